@@ -1,0 +1,114 @@
+/* typlonk.h -- C ABI of libtyplonk_hip.so: MI355X (gfx950) backend for TyPLONK's MSM + NTT hot path.
+ *
+ * The reference (fabrizio-m/TyPLONK, Rust) has no FFI of its own; these entry points are what a
+ * Rust `extern "C"` block would bind to replace the two seams named in SURVEY.md section 8(b):
+ *
+ *   MSM seam  kzg::KzgScheme::evaluate_in_s            /root/reference/kzg/src/lib.rs:41-54
+ *             (reached from commit :37-40, open :55-64, identity :82-85)
+ *   SRS       kzg::srs::Srs::g1 / g1_ref               /root/reference/kzg/src/srs.rs:8-12, 43-45
+ *   NTT seam  Evaluations::interpolate (ark-poly ifft) /root/reference/plonk/src/proof.rs:50,106,125,128,337,415
+ *             DensePolynomial::evaluate_over_domain    /root/reference/plonk/src/proof.rs:115
+ *
+ * Data formats (all little-endian, exactly arkworks 0.3.0's in-memory form, so a Rust caller passes
+ * `fr.0.0` / `pt.x.0.0` with no conversion):
+ *   Fr  : 4 x uint64 limbs, Montgomery residue, R = 2^256
+ *   Fq  : 6 x uint64 limbs, Montgomery residue, R = 2^384
+ *   G1  : 12 x uint64 = x limbs then y limbs, plus a separate flag byte (1 = point at infinity).
+ *         The identity is returned as x = 0, y = 1 (Montgomery one), inf = 1 -- ark-ec's
+ *         GroupAffine::zero().
+ *
+ * Conventions: every function returns TYPLONK_OK (0) or a negative error code; the caller owns all
+ * host buffers and the library never keeps a host pointer after returning; calls block until the
+ * result is on the host unless documented otherwise; one host thread per context.  Results are
+ * deterministic and bit-exact (modular integer arithmetic only).
+ */
+#ifndef TYPLONK_H
+#define TYPLONK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TYPLONK_OK 0
+#define TYPLONK_ERR_INVALID_ARG (-1)   /* NULL pointer, bad handle                                        */
+#define TYPLONK_ERR_LENGTH (-2)        /* m > srs length: the reference's assert!, kzg/src/lib.rs:43      */
+#define TYPLONK_ERR_DOMAIN (-3)        /* log_n outside 0..32: the reference's unwrap(), builder.rs:70    */
+#define TYPLONK_ERR_NO_DEVICE (-4)     /* no usable HIP device (the library has NO CPU fallback)          */
+#define TYPLONK_ERR_HIP (-5)           /* a HIP runtime call failed; see typlonk_last_error               */
+#define TYPLONK_ERR_OOM (-6)           /* device allocation failed                                        */
+#define TYPLONK_ERR_RANGE (-7)         /* offset/length outside a device buffer                            */
+
+typedef struct typlonk_ctx typlonk_ctx; /* one HIP device + stream + workspaces + cached NTT plans */
+typedef struct typlonk_buf typlonk_buf; /* device-resident vector of Fr elements                   */
+
+/* ---- context --------------------------------------------------------------------------------- */
+int typlonk_init(typlonk_ctx** out, int device_ordinal);
+void typlonk_destroy(typlonk_ctx* ctx);
+const char* typlonk_strerror(int code);
+const char* typlonk_last_error(const typlonk_ctx* ctx); /* detail text of the last failure on ctx  */
+/* Run all subsequent work of `ctx` on an existing hipStream_t (e.g. the caller's torch stream);
+ * NULL restores the context's own stream. */
+int typlonk_set_stream(typlonk_ctx* ctx, void* hip_stream);
+int typlonk_sync(typlonk_ctx* ctx);
+
+/* ---- SRS: the fixed MSM base vector ([s^i]G, affine), uploaded once per circuit ---------------- */
+/* xy: len*12 limbs; inf: len flag bytes or NULL (= no identity points).  Returns a handle id. */
+int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t len, uint32_t* srs_id);
+int typlonk_srs_free(typlonk_ctx* ctx, uint32_t srs_id);
+int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
+
+/* ---- MSM: sum_{i<m} scalars[i] * srs[i]  (== evaluate_in_s with coeffs = scalars) --------------- */
+/* scalars: m Fr elements (Montgomery).  0 <= m <= srs length, else TYPLONK_ERR_LENGTH.  m = 0 gives
+ * the identity (the reference's empty `.sum()`). */
+int typlonk_msm_g1(typlonk_ctx* ctx, uint32_t srs_id, const uint64_t* scalars, size_t m,
+                   uint64_t out_xy[12], uint8_t* out_inf);
+/* Same with the scalars already in HBM: a typlonk_buf range, or a raw device pointer. */
+int typlonk_msm_g1_dev(typlonk_ctx* ctx, uint32_t srs_id, const typlonk_buf* scalars, size_t offset, size_t m,
+                       uint64_t out_xy[12], uint8_t* out_inf);
+int typlonk_msm_g1_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scalars, size_t m,
+                          uint64_t out_xy[12], uint8_t* out_inf);
+
+/* ---- NTT over Fr: radix-2 domain of size 2^log_n with arkworks' generator -------------------------
+ * omega = TWO_ADIC_ROOT_OF_UNITY^(2^(32-log_n)).  Natural order in, natural order out, in place.
+ *   inverse = 0: data[k] <- sum_i data[i] * (g*omega^k)^i                (fft / coset_fft)
+ *   inverse = 1: data[i] <- g^-i * n^-1 * sum_k data[k] * omega^(-ik)    (ifft / coset_ifft)
+ * coset_shift: NULL (g = 1) or 4 limbs (Montgomery).  The caller zero-pads to 2^log_n. */
+int typlonk_ntt_fr(typlonk_ctx* ctx, uint64_t* data, uint32_t log_n, int inverse, const uint64_t* coset_shift);
+int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32_t log_n, int inverse,
+                       const uint64_t* coset_shift);
+int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int inverse,
+                          const uint64_t* coset_shift);
+
+/* ---- device-resident Fr vectors (so an iNTT result feeds an MSM without crossing PCIe) ---------- */
+int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out);
+int typlonk_buf_free(typlonk_ctx* ctx, typlonk_buf* buf);
+int typlonk_buf_upload(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, const uint64_t* src, size_t n_elems);
+int typlonk_buf_download(typlonk_ctx* ctx, const typlonk_buf* buf, size_t offset, uint64_t* dst, size_t n_elems);
+int typlonk_buf_zero(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, size_t n_elems);
+size_t typlonk_buf_len(const typlonk_buf* buf);
+void* typlonk_buf_devptr(const typlonk_buf* buf);
+
+/* ---- host-only helpers (no GPU needed) --------------------------------------------------------- */
+/* Fold `count` affine points in index order: the deterministic combine step after an all-gather of
+ * per-GPU partial MSM results (RCCL has no elliptic-curve reduction). */
+int typlonk_g1_sum_host(const uint64_t* xy, const uint8_t* inf, size_t count, uint64_t out_xy[12], uint8_t* out_inf);
+
+/* ---- measurement -------------------------------------------------------------------------------
+ * With profiling on, every kernel stage of the next MSM / NTT call is bracketed by HIP events on
+ * the context's stream.  typlonk_profile_get returns up to `cap` (name, milliseconds) pairs of the
+ * last call and the number of stages it had. */
+int typlonk_set_profiling(typlonk_ctx* ctx, int on);
+int typlonk_profile_get(typlonk_ctx* ctx, const char** names, float* ms, int cap);
+/* Pippenger shape chosen for an m-term MSM: window bits c, number of windows, and the number of
+ * group operations (mixed adds + full adds + doublings) the kernels execute for it. */
+int typlonk_msm_plan(typlonk_ctx* ctx, size_t m, uint32_t* window_bits, uint32_t* n_windows, uint64_t* group_ops);
+
+const char* typlonk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TYPLONK_H */

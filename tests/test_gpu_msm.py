@@ -1,0 +1,148 @@
+"""GPU parity of the MSM path (typlonk_msm_g1*) against the CPU oracle, through the C ABI.
+Small sizes: the oracle's reference-faithful naive MSM (kzg/src/lib.rs:41-54).  Larger sizes: the
+reference's own test identity commit(p) == [p(s)]G (kzg/src/lib.rs:102-105)."""
+import numpy as np
+import pytest
+
+from helpers import O, fr_pack, g1_pack, g1_unpack_one
+
+pytestmark = pytest.mark.gpu
+
+_srs_cache = {}
+
+
+def srs_points(s, length):
+    key = (s, length)
+    if key not in _srs_cache:
+        _srs_cache[key] = O.srs_from_secret_fast(s, length)
+    return _srs_cache[key]
+
+
+def load_srs(ctx, s, length):
+    pts = srs_points(s, length)
+    xy, inf = g1_pack(pts)
+    return ctx.srs_load(xy, inf), pts
+
+
+def commit_identity(coeffs, s):
+    return O.g1_mul(O.G1, O.poly_eval(coeffs, s))
+
+
+def test_kat1_commit_17G(ctx):
+    """kzg/src/lib.rs:95-109: s = 2, p = 1 + 2X + 3X^2 -> 17*G (literal coordinates, golden)."""
+    sid, pts = load_srs(ctx, 2, 13)
+    out, inf = ctx.msm(sid, fr_pack([1, 2, 3]))
+    got = g1_unpack_one(out, inf)
+    assert got == (
+        0x1098F178F84FC753A76BB63709E9BE91EEC3FF5F7F3A5F4836F34FE8A1A6D6C5578D8FD820573CEF3A01E2BFEF3EAF3A,
+        0x0EA923110B733B531006075F796CC9368F2477FE26020F465468EFBB380CE1F8EEBAF5C770F31D320F9BD378DC758436,
+    )
+    # open at z = 1: q = 3X + 5 -> 11 * G
+    q, y = O.poly_div_linear([1, 2, 3], 1)
+    assert y == 6 and q == [5, 3]
+    out, inf = ctx.msm(sid, fr_pack(q))
+    assert g1_unpack_one(out, inf) == O.g1_mul(O.G1, 11)
+    ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("m", [0, 1, 2, 3, 8, 33, 100])
+def test_small_vs_naive_oracle(ctx, m):
+    s = 0x0123456789ABCDEF0123456789ABCDEF
+    sid, pts = load_srs(ctx, s, 103)
+    coeffs = O.random_frs(0x5EED + m, m)
+    out, inf = ctx.msm(sid, fr_pack(coeffs) if m else np.zeros((0, 4), dtype=np.uint64), m)
+    got = g1_unpack_one(out, inf)
+    assert got == O.msm_naive(coeffs, pts)
+    if m == 0:
+        # identity encoding: x = 0, y = Montgomery one, inf = 1 (ark-ec GroupAffine::zero())
+        assert inf == 1 and not out[:6].any() and [int(x) for x in out[6:]] == O.fq_to_mont_limbs(1)
+    ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("m", [1000, 4093, (1 << 14) - 1, 1 << 14])
+def test_commit_identity(ctx, m):
+    sid, pts = load_srs(ctx, 2, (1 << 14) + 3)
+    coeffs = O.random_frs(0x5EED + m, m)
+    out, inf = ctx.msm(sid, fr_pack(coeffs))
+    assert g1_unpack_one(out, inf) == commit_identity(coeffs, 2)
+    ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("name", ["zeros", "ones", "r_minus_1", "single", "alternating", "short", "repeated"])
+def test_adversarial_scalars(ctx, name):
+    m = 1000
+    sid, pts = load_srs(ctx, 2, 1003)
+    rep = O.random_frs(42, 1)[0]
+    coeffs = {
+        "zeros": [0] * m,
+        "ones": [1] * m,
+        "r_minus_1": [O.R - 1] * m,
+        "single": [0] * 500 + [rep] + [0] * 499,
+        "alternating": [0 if i % 2 else O.R - 1 for i in range(m)],
+        "short": [x & 0xFFFF for x in O.random_frs(43, m)],
+        "repeated": [rep] * m,
+    }[name]
+    out, inf = ctx.msm(sid, fr_pack(coeffs))
+    assert g1_unpack_one(out, inf) == commit_identity(coeffs, 2)
+    ctx.srs_free(sid)
+
+
+def test_srs_with_identity_points(ctx):
+    """s = 0: SRS = [G, inf, inf, ...] (kzg/src/srs.rs:15-24 with s^i = 0)."""
+    pts = [O.G1] + [None] * 40
+    xy, inf = g1_pack(pts)
+    sid = ctx.srs_load(xy, inf)
+    coeffs = O.random_frs(5, 41)
+    out, oinf = ctx.msm(sid, fr_pack(coeffs))
+    assert g1_unpack_one(out, oinf) == O.g1_mul(O.G1, coeffs[0])
+    ctx.srs_free(sid)
+
+
+def test_srs_all_equal_points(ctx):
+    """s = 1: every base is G, so buckets hit the P + P doubling branch of the mixed add."""
+    pts = [O.G1] * 300
+    xy, inf = g1_pack(pts)
+    sid = ctx.srs_load(xy, None)
+    coeffs = O.random_frs(6, 300)
+    out, oinf = ctx.msm(sid, fr_pack(coeffs))
+    assert g1_unpack_one(out, oinf) == O.g1_mul(O.G1, sum(coeffs) % O.R)
+    # and P + (-P): scalars k, r-k on the same point cancel
+    coeffs = [5, O.R - 5, 7, O.R - 7]
+    out, oinf = ctx.msm(sid, fr_pack(coeffs))
+    assert g1_unpack_one(out, oinf) is None and oinf == 1
+    ctx.srs_free(sid)
+
+
+def test_scalar_mul_homomorphism(ctx):
+    """kzg/src/lib.rs:160-171: commit(9 p) == 9 commit(p)."""
+    sid, pts = load_srs(ctx, 2, 103)
+    p = O.random_frs(9, 8)
+    out1, i1 = ctx.msm(sid, fr_pack([9 * c % O.R for c in p]))
+    out2, i2 = ctx.msm(sid, fr_pack(p))
+    assert g1_unpack_one(out1, i1) == O.g1_mul(g1_unpack_one(out2, i2), 9)
+    ctx.srs_free(sid)
+
+
+def test_length_error_matches_reference_assert(ctx):
+    from typlonk_amd.capi import TyplonkError, ERR_LENGTH
+
+    sid, pts = load_srs(ctx, 2, 13)
+    with pytest.raises(TyplonkError) as e:
+        ctx.msm(sid, fr_pack([1] * 14))
+    assert e.value.code == ERR_LENGTH
+    ctx.srs_free(sid)
+
+
+def test_device_resident_intt_then_msm(ctx):
+    """interpolate(evals) -> commit without leaving HBM (plonk/src/builder.rs:85-86 pattern)."""
+    log_n, n = 10, 1 << 10
+    sid, pts = load_srs(ctx, 2, n + 3)
+    evals = O.random_frs(77, n)
+    buf = ctx.alloc(n)
+    buf.upload(fr_pack(evals))
+    ctx.ntt_dev(buf, log_n, inverse=True)
+    out, inf = ctx.msm_dev(sid, buf, 0, n)
+    coeffs = O.ntt(evals, log_n, inverse=True)
+    assert g1_unpack_one(out, inf) == commit_identity(coeffs, 2)
+    buf.free()
+    ctx.srs_free(sid)

@@ -1,0 +1,111 @@
+"""GPU parity of the NTT path (typlonk_ntt_fr*) against the CPU oracle, through the C ABI.
+Bit-exact: every comparison is integer equality of canonical Fr values / raw limbs."""
+import numpy as np
+import pytest
+
+from helpers import O, fr_pack, fr_unpack
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_limbs(seed, n):
+    """n valid Montgomery residues (any 256-bit value < r) straight from numpy"""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    return a
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 7, 8, 10, 11, 12, 13])
+def test_ntt_forward_inverse_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    v = O.random_frs(0x5EED + log_n, n)
+    f = ctx.ntt(fr_pack(v), log_n)
+    assert fr_unpack(f) == O.ntt(v, log_n)
+    i = ctx.ntt(fr_pack(v), log_n, inverse=True)
+    assert fr_unpack(i) == O.ntt(v, log_n, inverse=True)
+
+
+@pytest.mark.parametrize("log_n", [1, 3, 8, 10, 12])
+def test_coset_ntt_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    v = O.random_frs(0xC05E7 + log_n, n)
+    g = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
+    f = ctx.ntt(fr_pack(v), log_n, coset=g)
+    assert fr_unpack(f) == O.ntt(v, log_n, coset=7)
+    i = ctx.ntt(fr_pack(v), log_n, inverse=True, coset=g)
+    assert fr_unpack(i) == O.ntt(v, log_n, inverse=True, coset=7)
+
+
+def test_kat3_ntt4(ctx):
+    # SURVEY.md KAT-3 / tests/golden: NTT_4([1,2,3,4]) with arkworks' omega_4
+    out = fr_unpack(ctx.ntt(fr_pack([1, 2, 3, 4]), 2))
+    assert out == [0xA,
+                   0x73EDA753299D7D4718963E6B1D9BCE637BB7A3FE13F85BFEFFFDFFFEFFFFFFFF,
+                   0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFEFFFFFFFF,
+                   0x11AA3999CEC0609A1D8060004EC0600000001FFFFFFFFFFFE]
+
+
+def test_l0_identity_2_16(ctx):
+    """reference test plonk/src/utils.rs:161-177: L0 = (1/N) sum X^i evaluates to [1,0,...,0] on the
+    2^16 domain (sum of evaluations == 1)."""
+    log_n, n = 16, 1 << 16
+    ninv = pow(n, -1, O.R)
+    coeffs = np.tile(np.array(O.fr_to_mont_limbs(ninv), dtype=np.uint64), (n, 1))
+    ev = ctx.ntt(coeffs, log_n)
+    one = np.array(O.fr_to_mont_limbs(1), dtype=np.uint64)
+    assert (ev[0] == one).all()
+    assert not ev[1:].any()
+
+
+@pytest.mark.parametrize("log_n", [14, 16, 17, 20, 22])
+def test_roundtrip_and_spot_check_large(ctx, log_n):
+    n = 1 << log_n
+    x = rand_limbs(log_n, n)
+    f = ctx.ntt(x, log_n)
+    back = ctx.ntt(f, log_n, inverse=True)
+    assert (back == x).all()
+    # spot-check a few outputs against the definition X[k] = sum_i x[i] w^(ik), on a sparse input
+    sparse = np.zeros((n, 4), dtype=np.uint64)
+    idxs = [0, 1, 5, n // 3, n - 1]
+    vals = O.random_frs(99 + log_n, len(idxs))
+    for i, v in zip(idxs, vals):
+        sparse[i] = O.fr_to_mont_limbs(v)
+    fs = ctx.ntt(sparse, log_n)
+    w = O.domain_root(log_n)
+    for k in [0, 1, 2, n // 2 + 3, n - 1, 12345 % n]:
+        exp = sum(v * pow(w, i * k, O.R) for i, v in zip(idxs, vals)) % O.R
+        assert O.fr_from_mont_limbs([int(t) for t in fs[k]]) == exp
+
+
+def _to_int(row):
+    return sum(int(row[j]) << (64 * j) for j in range(4))
+
+
+def test_linearity_2_20(ctx):
+    """NTT(a + b) == NTT(a) + NTT(b) at 2^20 (Montgomery form is linear, so limbs add mod r)."""
+    log_n, n = 20, 1 << 20
+    a, b = rand_limbs(1, n), rand_limbs(2, n)
+    # a, b < 2^254 so a + b < 2^255: add as Python ints per element would be slow; do it with
+    # object arrays in bulk
+    ai = (a[:, 0].astype(object) + (a[:, 1].astype(object) << 64) + (a[:, 2].astype(object) << 128)
+          + (a[:, 3].astype(object) << 192))
+    bi = (b[:, 0].astype(object) + (b[:, 1].astype(object) << 64) + (b[:, 2].astype(object) << 128)
+          + (b[:, 3].astype(object) << 192))
+    si = (ai + bi) % O.R
+    s = np.empty((n, 4), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for j in range(4):
+        s[:, j] = ((si >> (64 * j)) & mask).astype(np.uint64)
+    fa, fb, fs = ctx.ntt(a, log_n), ctx.ntt(b, log_n), ctx.ntt(s, log_n)
+    rng = np.random.default_rng(7)
+    for k in [0, 1, n - 1] + [int(x) for x in rng.integers(0, n, size=64)]:
+        assert (_to_int(fa[k]) + _to_int(fb[k])) % O.R == _to_int(fs[k])
+
+
+def test_errors(ctx):
+    from typlonk_amd.capi import TyplonkError, ERR_DOMAIN
+
+    with pytest.raises(TyplonkError) as e:
+        ctx.ntt_devptr(1, 33)
+    assert e.value.code == ERR_DOMAIN

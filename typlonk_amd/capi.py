@@ -1,0 +1,264 @@
+"""ctypes binding of include/typlonk.h (libtyplonk_hip.so).  Plumbing only: device memory,
+streams and torch.distributed live in Python; every computation on the MSM/NTT path happens in the
+HIP library.  There is no CPU fallback: a missing library or device raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtyplonk_hip.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
+
+# every symbol include/typlonk.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
+    "typlonk_sync", "typlonk_srs_load", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
+    "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
+    "typlonk_ntt_fr_devptr", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
+    "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
+    "typlonk_version",
+]
+
+
+class TyplonkError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"typlonk error {code}: {detail}")
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the MSM/NTT path has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    u64p, u8p, vp = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.c_void_p
+    lib.typlonk_init.argtypes = [C.POINTER(vp), C.c_int]
+    lib.typlonk_destroy.argtypes = [vp]
+    lib.typlonk_destroy.restype = None
+    lib.typlonk_strerror.argtypes = [C.c_int]
+    lib.typlonk_strerror.restype = C.c_char_p
+    lib.typlonk_last_error.argtypes = [vp]
+    lib.typlonk_last_error.restype = C.c_char_p
+    lib.typlonk_set_stream.argtypes = [vp, vp]
+    lib.typlonk_sync.argtypes = [vp]
+    lib.typlonk_srs_load.argtypes = [vp, u64p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
+    lib.typlonk_srs_free.argtypes = [vp, C.c_uint32]
+    lib.typlonk_srs_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
+    lib.typlonk_msm_g1.argtypes = [vp, C.c_uint32, u64p, C.c_size_t, u64p, u8p]
+    lib.typlonk_msm_g1_dev.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.c_size_t, u64p, u8p]
+    lib.typlonk_msm_g1_devptr.argtypes = [vp, C.c_uint32, vp, C.c_size_t, u64p, u8p]
+    lib.typlonk_ntt_fr.argtypes = [vp, u64p, C.c_uint32, C.c_int, u64p]
+    lib.typlonk_ntt_fr_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int, u64p]
+    lib.typlonk_ntt_fr_devptr.argtypes = [vp, vp, C.c_uint32, C.c_int, u64p]
+    lib.typlonk_buf_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.typlonk_buf_free.argtypes = [vp, vp]
+    lib.typlonk_buf_upload.argtypes = [vp, vp, C.c_size_t, u64p, C.c_size_t]
+    lib.typlonk_buf_download.argtypes = [vp, vp, C.c_size_t, u64p, C.c_size_t]
+    lib.typlonk_buf_zero.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+    lib.typlonk_buf_len.argtypes = [vp]
+    lib.typlonk_buf_len.restype = C.c_size_t
+    lib.typlonk_buf_devptr.argtypes = [vp]
+    lib.typlonk_buf_devptr.restype = vp
+    lib.typlonk_g1_sum_host.argtypes = [u64p, u8p, C.c_size_t, u64p, u8p]
+    lib.typlonk_set_profiling.argtypes = [vp, C.c_int]
+    lib.typlonk_profile_get.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    lib.typlonk_msm_plan.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint64)]
+    lib.typlonk_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _u64p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _u8p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _as_u64(a, cols: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, cols)
+
+
+def g1_sum_host(xy, inf=None):
+    """Deterministic index-order fold of affine points (typlonk_g1_sum_host); no GPU needed."""
+    lib = load_library()
+    xy = _as_u64(xy, 12)
+    n = xy.shape[0]
+    infp = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        infp = _u8p(inf)
+    out = np.zeros(12, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    rc = lib.typlonk_g1_sum_host(_u64p(xy), infp, n, _u64p(out), _u8p(oinf))
+    if rc:
+        raise TyplonkError(rc, lib.typlonk_strerror(rc).decode())
+    return out, int(oinf[0])
+
+
+class DeviceBuffer:
+    """typlonk_buf: a device-resident vector of Fr elements."""
+
+    def __init__(self, ctx: "Context", n: int):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        ctx._chk(ctx.lib.typlonk_buf_alloc(ctx.h, n, C.byref(self.handle)))
+        self.n = n
+
+    def upload(self, arr, offset: int = 0):
+        arr = _as_u64(arr, 4)
+        self.ctx._chk(self.ctx.lib.typlonk_buf_upload(self.ctx.h, self.handle, offset, _u64p(arr), arr.shape[0]))
+
+    def download(self, offset: int = 0, n: int | None = None) -> np.ndarray:
+        n = self.n - offset if n is None else n
+        out = np.empty((n, 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.typlonk_buf_download(self.ctx.h, self.handle, offset, _u64p(out), n))
+        return out
+
+    def zero(self, offset: int = 0, n: int | None = None):
+        n = self.n - offset if n is None else n
+        self.ctx._chk(self.ctx.lib.typlonk_buf_zero(self.ctx.h, self.handle, offset, n))
+
+    @property
+    def devptr(self) -> int:
+        return self.ctx.lib.typlonk_buf_devptr(self.handle)
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.typlonk_buf_free(self.ctx.h, self.handle)
+            self.handle = C.c_void_p()
+
+
+class Context:
+    """typlonk_ctx: one HIP device, its stream, MSM workspaces and cached NTT plans."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.typlonk_init(C.byref(self.h), device)
+        if rc:
+            raise TyplonkError(rc, self.lib.typlonk_strerror(rc).decode())
+        self.device = device
+
+    def _chk(self, rc: int):
+        if rc < 0:
+            raise TyplonkError(rc, (self.lib.typlonk_strerror(rc).decode() + ": " +
+                                    self.lib.typlonk_last_error(self.h).decode()))
+        return rc
+
+    def close(self):
+        if self.h:
+            self.lib.typlonk_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle: int | None):
+        self._chk(self.lib.typlonk_set_stream(self.h, stream_handle))
+
+    def sync(self):
+        self._chk(self.lib.typlonk_sync(self.h))
+
+    # ---- SRS / MSM ------------------------------------------------------------------------
+    def srs_load(self, xy, inf=None) -> int:
+        xy = _as_u64(xy, 12)
+        infp = None
+        if inf is not None:
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+            infp = _u8p(inf)
+        sid = C.c_uint32()
+        self._chk(self.lib.typlonk_srs_load(self.h, _u64p(xy), infp, xy.shape[0], C.byref(sid)))
+        return sid.value
+
+    def srs_free(self, sid: int):
+        self._chk(self.lib.typlonk_srs_free(self.h, sid))
+
+    def srs_len(self, sid: int) -> int:
+        n = C.c_size_t()
+        self._chk(self.lib.typlonk_srs_len(self.h, sid, C.byref(n)))
+        return n.value
+
+    def msm(self, sid: int, scalars, m: int | None = None):
+        """host scalars (n,4) u64 Montgomery -> (xy[12] u64, inf)"""
+        scalars = _as_u64(scalars, 4)
+        m = scalars.shape[0] if m is None else m
+        out = np.zeros(12, dtype=np.uint64)
+        oinf = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.typlonk_msm_g1(self.h, sid, _u64p(scalars), m, _u64p(out), _u8p(oinf)))
+        return out, int(oinf[0])
+
+    def msm_dev(self, sid: int, buf: DeviceBuffer, offset: int, m: int):
+        out = np.zeros(12, dtype=np.uint64)
+        oinf = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.typlonk_msm_g1_dev(self.h, sid, buf.handle, offset, m, _u64p(out), _u8p(oinf)))
+        return out, int(oinf[0])
+
+    def msm_devptr(self, sid: int, devptr: int, m: int):
+        out = np.zeros(12, dtype=np.uint64)
+        oinf = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.typlonk_msm_g1_devptr(self.h, sid, devptr, m, _u64p(out), _u8p(oinf)))
+        return out, int(oinf[0])
+
+    def msm_plan(self, m: int):
+        c, w, ops = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self._chk(self.lib.typlonk_msm_plan(self.h, m, C.byref(c), C.byref(w), C.byref(ops)))
+        return c.value, w.value, ops.value
+
+    # ---- NTT ------------------------------------------------------------------------------
+    @staticmethod
+    def _coset(coset):
+        if coset is None:
+            return None, None
+        a = np.ascontiguousarray(coset, dtype=np.uint64).reshape(4)
+        return a, _u64p(a)
+
+    def ntt(self, data, log_n: int, inverse: bool = False, coset=None) -> np.ndarray:
+        """host vector (2^log_n, 4) u64 -> transformed copy"""
+        data = _as_u64(data, 4).copy()
+        if data.shape[0] != (1 << log_n):
+            raise ValueError("data length must be 2^log_n (caller zero-pads)")
+        keep, cp = self._coset(coset)
+        self._chk(self.lib.typlonk_ntt_fr(self.h, _u64p(data), log_n, int(inverse), cp))
+        return data
+
+    def ntt_dev(self, buf: DeviceBuffer, log_n: int, inverse: bool = False, coset=None, offset: int = 0):
+        keep, cp = self._coset(coset)
+        self._chk(self.lib.typlonk_ntt_fr_dev(self.h, buf.handle, offset, log_n, int(inverse), cp))
+
+    def ntt_devptr(self, devptr: int, log_n: int, inverse: bool = False, coset=None):
+        keep, cp = self._coset(coset)
+        self._chk(self.lib.typlonk_ntt_fr_devptr(self.h, devptr, log_n, int(inverse), cp))
+
+    def alloc(self, n: int) -> DeviceBuffer:
+        return DeviceBuffer(self, n)
+
+    # ---- measurement ----------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._chk(self.lib.typlonk_set_profiling(self.h, int(on)))
+
+    def profile(self) -> list[tuple[str, float]]:
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = self._chk(self.lib.typlonk_profile_get(self.h, names, ms, cap))
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n, cap))]

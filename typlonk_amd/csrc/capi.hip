@@ -1,0 +1,745 @@
+// libtyplonk_hip.so -- implementation of include/typlonk.h for gfx950.
+// Host driver: context/workspace management, NTT planning + twiddle tables, MSM staging and the
+// final (host) window combine.  There is deliberately no CPU compute fallback: without a HIP
+// device typlonk_init fails with TYPLONK_ERR_NO_DEVICE.
+#include "../../include/typlonk.h"
+#include "msm_kernels.hpp"
+#include "ntt_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ty;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct SrsEntry {
+    uint32_t* d_points = nullptr;  // len * 24 u32, identity encoded (0,0)
+    size_t len = 0;
+};
+
+struct Table {
+    Fr* d = nullptr;
+    size_t n = 0;
+};
+
+struct ProfStage {
+    const char* name;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct typlonk_buf {
+    Fr* d = nullptr;
+    size_t n = 0;
+};
+
+struct typlonk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<uint32_t, SrsEntry> srs;
+    uint32_t next_srs = 1;
+    // MSM workspaces (grow-only)
+    DevBuf scal, keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b;
+    // NTT
+    DevBuf ntt_scratch, ntt_io;
+    std::map<std::string, Table> tables;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfStage> prof;
+    std::vector<std::pair<const char*, float>> prof_result;
+    int msm_c_override = 0;
+};
+
+namespace {
+
+int fail(typlonk_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(ctx, _e == hipErrorOutOfMemory ? TYPLONK_ERR_OOM : TYPLONK_ERR_HIP,               \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                               \
+    } while (0)
+
+int ensure(typlonk_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.cap >= bytes) return TYPLONK_OK;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return TYPLONK_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+struct StageTimer {
+    typlonk_ctx* ctx;
+    bool on;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char* name;
+    StageTimer(typlonk_ctx* c, const char* n) : ctx(c), on(c->profiling), name(n) {
+        if (on) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~StageTimer() {
+        if (on) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->prof.push_back({name, a, b});
+        }
+    }
+};
+
+void prof_begin(typlonk_ctx* ctx) {
+    for (auto& s : ctx->prof) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    ctx->prof.clear();
+}
+
+void prof_collect(typlonk_ctx* ctx) {
+    if (!ctx->profiling) return;
+    ctx->prof_result.clear();
+    for (auto& s : ctx->prof) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(s.b);
+        (void)hipEventElapsedTime(&ms, s.a, s.b);
+        ctx->prof_result.push_back({s.name, ms});
+    }
+    prof_begin(ctx);
+}
+
+// ---- host Fr helpers ---------------------------------------------------------------------------
+Fr fr_root_of_unity_2_32() {
+    // ark-bls12-381 FrParameters::TWO_ADIC_ROOT_OF_UNITY = 7^((r-1)/2^32), canonical value
+    Fr c;
+    const uint32_t limbs[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u,
+                               0x22c813b4u, 0xd09b6819u, 0xdfe81f20u, 0x16a2a19eu};
+    for (int i = 0; i < 8; ++i) c.v[i] = limbs[i];
+    return fe_to_mont(c);
+}
+
+// generator of the size-2^log_n domain (ark-poly Radix2EvaluationDomain::group_gen)
+Fr fr_domain_root(uint32_t log_n) {
+    Fr w = fr_root_of_unity_2_32();
+    for (uint32_t i = log_n; i < 32; ++i) w = fe_sqr(w);
+    return w;
+}
+
+Fr fr_from_u64(uint64_t x) {
+    Fr c = Fr::zero();
+    c.v[0] = (uint32_t)x;
+    c.v[1] = (uint32_t)(x >> 32);
+    return fe_to_mont(c);
+}
+
+int upload_table(typlonk_ctx* ctx, const std::string& key, const std::vector<Fr>& h, Table* out) {
+    Table t;
+    t.n = h.size();
+    HIPCHK(hipMalloc((void**)&t.d, h.size() * sizeof(Fr)));
+    HIPCHK(hipMemcpyAsync(t.d, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // h goes out of scope
+    ctx->tables[key] = t;
+    *out = t;
+    return TYPLONK_OK;
+}
+
+// powers table: out[j] = scale * base^j, j < n
+int get_pow_table(typlonk_ctx* ctx, const std::string& key, const Fr& base, const Fr& scale, size_t n, Table* out) {
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return TYPLONK_OK;
+    }
+    std::vector<Fr> h(n);
+    Fr x = scale;
+    for (size_t j = 0; j < n; ++j) {
+        h[j] = x;
+        x = fe_mul(x, base);
+    }
+    return upload_table(ctx, key, h, out);
+}
+
+std::string fr_hex(const Fr& f) {
+    char buf[80];
+    snprintf(buf, sizeof(buf), "%08x%08x%08x%08x%08x%08x%08x%08x", f.v[7], f.v[6], f.v[5], f.v[4], f.v[3], f.v[2],
+             f.v[1], f.v[0]);
+    return buf;
+}
+
+// two-level power tables of `base` covering exponents < 2^log_len:
+//   lo[j] = base^j (j < 2^h),  hi[j] = hi_scale * base^(j * 2^h) (j < 2^(log_len-h))
+int get_pow2l(typlonk_ctx* ctx, const std::string& key, const Fr& base, const Fr& hi_scale, uint32_t log_len,
+              Table* lo, Table* hi, uint32_t* h_out) {
+    const uint32_t h = (log_len + 1) / 2;
+    *h_out = h;
+    int rc = get_pow_table(ctx, key + ":lo", base, Fr::one(), (size_t)1 << h, lo);
+    if (rc) return rc;
+    Fr step = base;
+    for (uint32_t i = 0; i < h; ++i) step = fe_sqr(step);
+    return get_pow_table(ctx, key + ":hi", step, hi_scale, (size_t)1 << (log_len - h), hi);
+}
+
+void split_log(uint32_t L, uint32_t ks[4], uint32_t* P) {
+    uint32_t p = L <= 10 ? 1 : (L <= 16 ? 2 : (L <= 24 ? 3 : 4));
+    *P = p;
+    for (uint32_t i = 0; i < p; ++i) ks[i] = L / p + (i < L % p ? 1 : 0);
+}
+
+uint32_t ilog2_u64(uint64_t x) {
+    uint32_t r = 0;
+    while ((1ull << (r + 1)) <= x) ++r;
+    return r;
+}
+
+int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift) {
+    if (log_n > 32) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 32 (Fr two-adicity)");
+    if (!d_data) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null data");
+    prof_begin(ctx);
+    if (log_n == 0) {
+        prof_collect(ctx);
+        return TYPLONK_OK;  // size-1 transform is the identity (g^0 = 1, n^-1 = 1)
+    }
+    const uint64_t N = 1ull << log_n;
+    uint32_t ks[4], P;
+    split_log(log_n, ks, &P);
+    const std::string dir = inverse ? "i" : "f";
+
+    Fr* scratch = nullptr;
+    if (P >= 2) {
+        int rc = ensure(ctx, ctx->ntt_scratch, N * sizeof(Fr));
+        if (rc) return rc;
+        scratch = (Fr*)ctx->ntt_scratch.p;
+    }
+
+    // coset / scaling tables
+    Table pre_lo{}, pre_hi{}, post_lo{}, post_hi{}, scale{};
+    uint32_t pre_h = 0, post_h = 0;
+    Fr n_inv = Fr::one();
+    if (inverse) n_inv = fe_inv(fr_from_u64(N));
+    if (coset_shift) {
+        Fr g;
+        memcpy(g.v, coset_shift, sizeof(g.v));
+        if (!inverse) {
+            int rc = get_pow2l(ctx, "cs:f:" + std::to_string(log_n) + ":" + fr_hex(g), g, Fr::one(), log_n, &pre_lo,
+                               &pre_hi, &pre_h);
+            if (rc) return rc;
+        } else {
+            Fr gi = fe_inv(g);
+            int rc = get_pow2l(ctx, "cs:i:" + std::to_string(log_n) + ":" + fr_hex(g), gi, n_inv, log_n, &post_lo,
+                               &post_hi, &post_h);
+            if (rc) return rc;
+        }
+    } else if (inverse) {
+        int rc = get_pow_table(ctx, "ninv:" + std::to_string(log_n), Fr::one(), n_inv, 1, &scale);
+        if (rc) return rc;
+    }
+
+    uint64_t row_len = N;  // length of the rows the current pass works inside
+    uint64_t rows = 1;
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t k = ks[p];
+        const uint64_t M = 1ull << k;
+        const bool last = (p + 1 == P);
+        NttPassArgs a{};
+        a.k = k;
+        a.last = last ? 1 : 0;
+        a.S = row_len / M;
+        a.row_len = row_len;
+        // sub-transform twiddles w_M^e
+        {
+            Fr w = fr_domain_root(k);
+            if (inverse) w = fe_inv(w);
+            Table t;
+            int rc = get_pow_table(ctx, "sub:" + dir + ":" + std::to_string(k), w, Fr::one(), (size_t)std::max<uint64_t>(M / 2, 1), &t);
+            if (rc) return rc;
+            a.sub_tw = t.d;
+        }
+        uint32_t logT;
+        if (!last) {
+            const uint32_t lrow = ilog2_u64(row_len);
+            Fr w = fr_domain_root(lrow);
+            if (inverse) w = fe_inv(w);
+            Table lo, hi;
+            int rc = get_pow2l(ctx, "tw:" + dir + ":" + std::to_string(lrow), w, Fr::one(), lrow, &lo, &hi, &a.tw_h);
+            if (rc) return rc;
+            a.tw_lo = lo.d;
+            a.tw_hi = hi.d;
+            logT = std::min<uint32_t>(10 - k, ilog2_u64(a.S));
+        } else {
+            const uint64_t N1 = 1ull << ks[0];
+            a.N1 = (P == 1) ? 1 : N1;
+            a.Q = (P <= 2) ? 1 : rows / N1;
+            a.N2 = (P >= 3) ? (1ull << ks[1]) : 1;
+            a.N3 = (P == 4) ? (1ull << ks[2]) : 1;
+            a.out_stride = N / M;
+            logT = (P == 1) ? 0 : std::min<uint32_t>(10 - k, ks[0]);
+            a.post_lo = post_lo.d;
+            a.post_hi = post_hi.d;
+            a.post_h = post_h;
+            a.scale = scale.d;
+        }
+        a.logT = logT;
+        if (p == 0) {
+            a.pre_lo = pre_lo.d;
+            a.pre_hi = pre_hi.d;
+            a.pre_h = pre_h;
+        }
+        if (P == 1) {
+            a.in = d_data;
+            a.out = d_data;
+        } else if (p == 0) {
+            a.in = d_data;
+            a.out = scratch;
+        } else if (!last) {
+            a.in = scratch;
+            a.out = scratch;
+        } else {
+            a.in = scratch;
+            a.out = d_data;
+        }
+        const uint64_t E = M << logT;
+        const uint64_t blocks = N / E;
+        const size_t lds = (size_t)(E + std::max<uint64_t>(M / 2, 1)) * sizeof(Fr);
+        {
+            static const char* names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
+            StageTimer st(ctx, names[p]);
+            hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)blocks), dim3(NTT_THREADS), lds, ctx->stream, a);
+        }
+        HIPCHK(hipGetLastError());
+        rows *= M;
+        row_len /= M;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    return TYPLONK_OK;
+}
+
+// ---- MSM ------------------------------------------------------------------------------------
+void msm_shape(typlonk_ctx* ctx, size_t m, uint32_t* c_out, uint32_t* w_out) {
+    uint32_t lg = 0;
+    while (((size_t)1 << (lg + 1)) <= m) ++lg;
+    int c = (int)lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    if (ctx && ctx->msm_c_override) c = ctx->msm_c_override;
+    *c_out = (uint32_t)c;
+    *w_out = (256 + c - 1) / c;
+}
+
+void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf) {
+    if (a.is_inf()) {
+        // ark-ec GroupAffine::zero(): x = 0, y = 1 (Montgomery one), infinity = true
+        Fq one = Fq::one();
+        memset(out_xy, 0, 6 * sizeof(uint64_t));
+        memcpy(out_xy + 6, one.v, sizeof(one.v));
+        *out_inf = 1;
+    } else {
+        memcpy(out_xy, a.x.v, sizeof(a.x.v));
+        memcpy(out_xy + 6, a.y.v, sizeof(a.y.v));
+        *out_inf = 0;
+    }
+}
+
+int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12],
+            uint8_t* out_inf) {
+    if (!out_xy || !out_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    const SrsEntry& srs = it->second;
+    if (m > srs.len) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
+    prof_begin(ctx);
+    if (m == 0) {
+        write_affine_out(G1Affine::inf(), out_xy, out_inf);
+        prof_collect(ctx);
+        return TYPLONK_OK;
+    }
+    if (!d_scalars) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null scalars");
+    uint32_t c, W;
+    msm_shape(ctx, m, &c, &W);
+    const uint32_t B = 1u << (c - 1);
+    const uint64_t nb = (uint64_t)W * B;
+    const uint64_t total = (uint64_t)W * m;
+    if (total >= (1ull << 31)) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM too large for 32-bit entry indices");
+    const uint32_t L = std::min<uint32_t>(MSM_SEG, B);
+    const uint32_t npw = B / L;
+    const uint32_t nodes = W * npw;
+    const uint32_t scan_blocks = (uint32_t)((nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+
+    int rc;
+    if ((rc = ensure(ctx, ctx->keys, total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sorted, total * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->counts, nb * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->offsets, (nb + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cursor, nb * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->blocksums, (size_t)scan_blocks * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->buckets, nb * 192))) return rc;
+    if ((rc = ensure(ctx, ctx->part_a, (size_t)nodes * 192))) return rc;
+    if ((rc = ensure(ctx, ctx->part_b, (size_t)nodes * 192))) return rc;
+
+    uint32_t* keys = (uint32_t*)ctx->keys.p;
+    uint32_t* sorted = (uint32_t*)ctx->sorted.p;
+    uint32_t* counts = (uint32_t*)ctx->counts.p;
+    uint32_t* offsets = (uint32_t*)ctx->offsets.p;
+    uint32_t* cursor = (uint32_t*)ctx->cursor.p;
+    uint32_t* blocksums = (uint32_t*)ctx->blocksums.p;
+    uint32_t* buckets = (uint32_t*)ctx->buckets.p;
+    uint32_t* pa = (uint32_t*)ctx->part_a.p;
+    uint32_t* pb = (uint32_t*)ctx->part_b.p;
+    hipStream_t s = ctx->stream;
+
+    {
+        StageTimer st(ctx, "msm_digits");
+        HIPCHK(hipMemsetAsync(counts, 0, nb * 4, s));
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((m + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
+                           0, s, d_scalars, (uint64_t)m, c, W, keys, counts);
+    }
+    {
+        StageTimer st(ctx, "msm_scan");
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(scan_blocks), dim3(256), 0, s, counts, nb, blocksums);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, blocksums, scan_blocks);
+        hipLaunchKernelGGL(scan_finish_kernel, dim3(scan_blocks), dim3(256), 0, s, counts, nb, blocksums, offsets,
+                           cursor);
+    }
+    {
+        StageTimer st(ctx, "msm_scatter");
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((total + MSM_THREADS - 1) / MSM_THREADS)),
+                           dim3(MSM_THREADS), 0, s, keys, (uint64_t)m, total, cursor, sorted);
+    }
+    {
+        StageTimer st(ctx, "msm_accum");
+        hipLaunchKernelGGL(msm_accum_kernel, dim3((unsigned)((nb + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
+                           dim3(MSM_ACC_THREADS), 0, s, srs.d_points, offsets, sorted, (uint32_t)nb, buckets);
+    }
+    uint32_t* cur = pa;
+    uint32_t* other = pb;
+    uint32_t n_in;
+    {
+        StageTimer st(ctx, "msm_reduce");
+        const uint32_t group = std::min<uint32_t>(64, npw);
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3((nodes + 63) / 64), dim3(64), 0, s, buckets, B, L, nodes, group, c,
+                           cur);
+        n_in = npw / group;
+        while (n_in > 1) {
+            const uint32_t g2 = std::min<uint32_t>(64, n_in);
+            const uint32_t tot = W * n_in;
+            hipLaunchKernelGGL(msm_fold_kernel, dim3((tot + 63) / 64), dim3(64), 0, s, cur, tot, g2, other);
+            std::swap(cur, other);
+            n_in /= g2;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<G1Xyzz> wins(W);
+    HIPCHK(hipMemcpyAsync(wins.data(), cur, (size_t)W * 192, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // host: sum_j 2^(c*j) * wins[j]  (Horner from the top window), then canonical affine
+    G1Xyzz acc = G1Xyzz::inf();
+    for (int j = (int)W - 1; j >= 0; --j) {
+        if (!acc.is_inf())
+            for (uint32_t d = 0; d < c; ++d) acc = g1_dbl(acc);
+        acc = g1_add(acc, wins[j]);
+    }
+    write_affine_out(g1_to_affine(acc), out_xy, out_inf);
+    prof_collect(ctx);
+    return TYPLONK_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* typlonk_version(void) { return "typlonk-mi355x 0.1 (gfx950)"; }
+
+const char* typlonk_strerror(int code) {
+    switch (code) {
+        case TYPLONK_OK: return "ok";
+        case TYPLONK_ERR_INVALID_ARG: return "invalid argument";
+        case TYPLONK_ERR_LENGTH: return "MSM length exceeds SRS length";
+        case TYPLONK_ERR_DOMAIN: return "unsupported evaluation-domain size";
+        case TYPLONK_ERR_NO_DEVICE: return "no HIP device available (no CPU fallback)";
+        case TYPLONK_ERR_HIP: return "HIP runtime error";
+        case TYPLONK_ERR_OOM: return "device out of memory";
+        case TYPLONK_ERR_RANGE: return "range outside device buffer";
+        default: return "unknown error";
+    }
+}
+
+const char* typlonk_last_error(const typlonk_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int typlonk_init(typlonk_ctx** out, int device_ordinal) {
+    if (!out) return TYPLONK_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TYPLONK_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= count) return TYPLONK_ERR_INVALID_ARG;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return TYPLONK_ERR_HIP;
+    typlonk_ctx* ctx = new typlonk_ctx();
+    ctx->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return TYPLONK_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    if (const char* e = getenv("TYPLONK_MSM_C")) {
+        int c = atoi(e);
+        if (c >= 4 && c <= 20) ctx->msm_c_override = c;
+    }
+    *out = ctx;
+    return TYPLONK_OK;
+}
+
+void typlonk_destroy(typlonk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_begin(ctx);
+    for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
+    for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
+    for (DevBuf* b : {&ctx->scal, &ctx->keys, &ctx->sorted, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->blocksums,
+                      &ctx->buckets, &ctx->part_a, &ctx->part_b, &ctx->ntt_scratch, &ctx->ntt_io})
+        release(*b);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int typlonk_set_stream(typlonk_ctx* ctx, void* hip_stream) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return TYPLONK_OK;
+}
+
+int typlonk_sync(typlonk_ctx* ctx) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return TYPLONK_OK;
+}
+
+int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t len, uint32_t* srs_id) {
+    if (!ctx || !srs_id || (!xy && len)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    SrsEntry e;
+    e.len = len;
+    HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * 96));
+    if (len) {
+        HIPCHK(hipMemcpyAsync(e.d_points, xy, len * 96, hipMemcpyHostToDevice, ctx->stream));
+        if (inf) {
+            uint8_t* d_inf = nullptr;
+            HIPCHK(hipMalloc((void**)&d_inf, len));
+            HIPCHK(hipMemcpyAsync(d_inf, inf, len, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(msm_mark_inf_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream,
+                               e.d_points, d_inf, (uint64_t)len);
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipFree(d_inf));
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    const uint32_t id = ctx->next_srs++;
+    ctx->srs[id] = e;
+    *srs_id = id;
+    return TYPLONK_OK;
+}
+
+int typlonk_srs_free(typlonk_ctx* ctx, uint32_t srs_id) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(it->second.d_points));
+    ctx->srs.erase(it);
+    return TYPLONK_OK;
+}
+
+int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len) {
+    if (!ctx || !len) return TYPLONK_ERR_INVALID_ARG;
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    *len = it->second.len;
+    return TYPLONK_OK;
+}
+
+int typlonk_msm_g1_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scalars, size_t m, uint64_t out_xy[12],
+                          uint8_t* out_inf) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return msm_run(ctx, srs_id, (const Fr*)d_scalars, m, out_xy, out_inf);
+}
+
+int typlonk_msm_g1_dev(typlonk_ctx* ctx, uint32_t srs_id, const typlonk_buf* scalars, size_t offset, size_t m,
+                       uint64_t out_xy[12], uint8_t* out_inf) {
+    if (!ctx || !scalars) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (offset > scalars->n || m > scalars->n - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside buffer");
+    HIPCHK(hipSetDevice(ctx->device));
+    return msm_run(ctx, srs_id, scalars->d + offset, m, out_xy, out_inf);
+}
+
+int typlonk_msm_g1(typlonk_ctx* ctx, uint32_t srs_id, const uint64_t* scalars, size_t m, uint64_t out_xy[12],
+                   uint8_t* out_inf) {
+    if (!ctx || (!scalars && m)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    // validate the length before touching the device so the error matches the reference's assert
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    if (m > it->second.len) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
+    if (m) {
+        int rc = ensure(ctx, ctx->scal, m * sizeof(Fr));
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->scal.p, scalars, m * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    }
+    return msm_run(ctx, srs_id, (const Fr*)ctx->scal.p, m, out_xy, out_inf);
+}
+
+int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return ntt_run(ctx, (Fr*)d_data, log_n, inverse, coset_shift);
+}
+
+int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32_t log_n, int inverse,
+                       const uint64_t* coset_shift) {
+    if (!ctx || !buf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (log_n > 32) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 32 (Fr two-adicity)");
+    const uint64_t N = 1ull << log_n;
+    if (offset > buf->n || N > buf->n - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside buffer");
+    HIPCHK(hipSetDevice(ctx->device));
+    return ntt_run(ctx, buf->d + offset, log_n, inverse, coset_shift);
+}
+
+int typlonk_ntt_fr(typlonk_ctx* ctx, uint64_t* data, uint32_t log_n, int inverse, const uint64_t* coset_shift) {
+    if (!ctx || !data) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (log_n > 32) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 32 (Fr two-adicity)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = ((size_t)1 << log_n) * sizeof(Fr);
+    int rc = ensure(ctx, ctx->ntt_io, bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->ntt_io.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = ntt_run(ctx, (Fr*)ctx->ntt_io.p, log_n, inverse, coset_shift);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(data, ctx->ntt_io.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return TYPLONK_OK;
+}
+
+int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out) {
+    if (!ctx || !out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    typlonk_buf* b = new typlonk_buf();
+    b->n = n_elems;
+    hipError_t e = hipMalloc((void**)&b->d, std::max<size_t>(n_elems, 1) * sizeof(Fr));
+    if (e != hipSuccess) {
+        delete b;
+        return fail(ctx, TYPLONK_ERR_OOM, hipGetErrorString(e));
+    }
+    *out = b;
+    return TYPLONK_OK;
+}
+
+int typlonk_buf_free(typlonk_ctx* ctx, typlonk_buf* buf) {
+    if (!ctx || !buf) return TYPLONK_ERR_INVALID_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(buf->d));
+    delete buf;
+    return TYPLONK_OK;
+}
+
+int typlonk_buf_upload(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, const uint64_t* src, size_t n_elems) {
+    if (!ctx || !buf || (!src && n_elems)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (offset > buf->n || n_elems > buf->n - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside buffer");
+    if (!n_elems) return TYPLONK_OK;
+    HIPCHK(hipMemcpyAsync(buf->d + offset, src, n_elems * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return TYPLONK_OK;
+}
+
+int typlonk_buf_download(typlonk_ctx* ctx, const typlonk_buf* buf, size_t offset, uint64_t* dst, size_t n_elems) {
+    if (!ctx || !buf || (!dst && n_elems)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (offset > buf->n || n_elems > buf->n - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside buffer");
+    if (!n_elems) return TYPLONK_OK;
+    HIPCHK(hipMemcpyAsync(dst, buf->d + offset, n_elems * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return TYPLONK_OK;
+}
+
+int typlonk_buf_zero(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, size_t n_elems) {
+    if (!ctx || !buf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (offset > buf->n || n_elems > buf->n - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside buffer");
+    if (!n_elems) return TYPLONK_OK;
+    HIPCHK(hipMemsetAsync(buf->d + offset, 0, n_elems * sizeof(Fr), ctx->stream));
+    return TYPLONK_OK;
+}
+
+size_t typlonk_buf_len(const typlonk_buf* buf) { return buf ? buf->n : 0; }
+void* typlonk_buf_devptr(const typlonk_buf* buf) { return buf ? (void*)buf->d : nullptr; }
+
+int typlonk_g1_sum_host(const uint64_t* xy, const uint8_t* inf, size_t count, uint64_t out_xy[12], uint8_t* out_inf) {
+    if ((!xy && count) || !out_xy || !out_inf) return TYPLONK_ERR_INVALID_ARG;
+    G1Xyzz acc = G1Xyzz::inf();
+    for (size_t i = 0; i < count; ++i) {
+        if (inf && inf[i]) continue;
+        G1Affine p;
+        memcpy(p.x.v, xy + i * 12, sizeof(p.x.v));
+        memcpy(p.y.v, xy + i * 12 + 6, sizeof(p.y.v));
+        g1_madd(acc, p, false);
+    }
+    write_affine_out(g1_to_affine(acc), out_xy, out_inf);
+    return TYPLONK_OK;
+}
+
+int typlonk_set_profiling(typlonk_ctx* ctx, int on) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    ctx->profiling = on != 0;
+    return TYPLONK_OK;
+}
+
+int typlonk_profile_get(typlonk_ctx* ctx, const char** names, float* ms, int cap) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    const int n = (int)ctx->prof_result.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = ctx->prof_result[i].first;
+        if (ms) ms[i] = ctx->prof_result[i].second;
+    }
+    return n;
+}
+
+int typlonk_msm_plan(typlonk_ctx* ctx, size_t m, uint32_t* window_bits, uint32_t* n_windows, uint64_t* group_ops) {
+    uint32_t c, W;
+    msm_shape(ctx, m ? m : 1, &c, &W);
+    if (window_bits) *window_bits = c;
+    if (n_windows) *n_windows = W;
+    // Pippenger operation count for this shape: one mixed add per (term, window), two adds per
+    // bucket in the running-sum reduction, c doublings per window in the final combine.
+    if (group_ops) *group_ops = (uint64_t)W * m + 2ull * W * (1ull << (c - 1)) + (uint64_t)c * (W - 1);
+    return TYPLONK_OK;
+}
+
+}  // extern "C"

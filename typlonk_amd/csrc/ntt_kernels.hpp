@@ -1,0 +1,143 @@
+// Radix-2 NTT over Fr as a Bailey-style multi-pass transform (replaces ark-poly 0.3.0
+// Radix2EvaluationDomain::{fft,ifft}; reference call sites /root/reference/plonk/src/proof.rs:50,
+// 106, 115, 125, 128, 337, 415 and plonk/src/builder.rs:85).
+//
+// N = N_1 * N_2 * ... * N_P (P <= 4, N_p = 2^k_p <= 2^10).  With the input index written
+// i = (i_1, i_2, ..., i_P) most-significant first and the output index k = (k_P, ..., k_2, k_1):
+//   pass p < P : for every (k_1..k_{p-1}) row and every column r = (i_{p+1}..i_P), a size-N_p NTT
+//                over i_p (stride S_p = N / (N_1..N_p)), times the inter-pass twiddle
+//                w_{row_len}^(r * k_p), written back to the same positions (in place per tile);
+//   pass P     : contiguous size-N_P NTTs; the store performs the digit reversal so the result
+//                lands in natural order: out[k_1 + N_1 k_2 + ... + (N/N_P) k_P].
+// Every global access moves >= 128-B contiguous chunks (a workgroup owns a tile of T adjacent
+// columns / T rows whose outputs are adjacent), the butterflies run on an LDS-resident tile of
+// 1024 elements (32 KiB) and the sub-transform's twiddles w_{N_p}^e are staged in LDS.
+// Inter-pass twiddles and coset powers come from two-level tables (lo[e & mask] * hi[e >> h]),
+// each <= 2^ceil(log/2) entries, so they stay in L2.
+#pragma once
+#include "ff.hpp"
+
+namespace ty {
+
+struct NttPassArgs {
+    const Fr* in;
+    Fr* out;
+    uint32_t k;        // log2 of this pass's sub-transform size M
+    uint32_t logT;     // log2 of the tile width T
+    uint32_t last;     // 1 for the final (contiguous, digit-reversing) pass
+    uint32_t tw_h;     // split of the inter-pass twiddle exponent
+    uint64_t S;        // stride between consecutive i_p (elements); 1 on the last pass
+    uint64_t row_len;  // M * S
+    // last pass addressing: row rho = k_1 * Q + q ; out = k_1 + N1 * qrev(q) + out_stride * k_P
+    uint64_t N1, Q, N2, N3, out_stride;
+    const Fr* sub_tw;  // w_M^e, e < M/2
+    const Fr* tw_lo;   // w_{row_len}^e,          e < 2^tw_h
+    const Fr* tw_hi;   // w_{row_len}^(e * 2^tw_h)
+    const Fr* pre_lo;  // coset powers g^i applied to the input of pass 1 (forward coset NTT)
+    const Fr* pre_hi;
+    const Fr* post_lo; // g^-k * n^-1 applied to the output of the last pass (inverse coset NTT)
+    const Fr* post_hi;
+    const Fr* scale;   // n^-1 applied to the output of the last pass (plain inverse NTT)
+    uint32_t pre_h, post_h;
+};
+
+__device__ __forceinline__ Fr ntt_ld(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void ntt_st(Fr* p, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+__device__ __forceinline__ Fr ntt_pow2l(const Fr* lo, const Fr* hi, uint32_t h, uint64_t e) {
+    return fe_mul(ntt_ld(lo + (e & ((1ull << h) - 1))), ntt_ld(hi + (e >> h)));
+}
+
+constexpr int NTT_THREADS = 256;
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
+    const uint32_t k = a.k, logT = a.logT;
+    const uint32_t M = 1u << k, T = 1u << logT, E = M << logT;
+    Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
+    Fr* stw = tile + E;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+
+    for (uint32_t i = tid; i < (M >> 1); i += NTT_THREADS) ntt_st(stw + i, ntt_ld(a.sub_tw + i));
+
+    uint64_t base = 0, c0 = 0, q = 0, k1base = 0;
+    if (!a.last) {
+        const uint64_t tiles_per_row = a.S >> logT;
+        const uint64_t row = b / tiles_per_row;
+        c0 = (b % tiles_per_row) << logT;
+        base = row * a.row_len + c0;
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t t = idx & (T - 1), i = idx >> logT;
+            const uint64_t g = base + (uint64_t)i * a.S + t;
+            Fr x = ntt_ld(a.in + g);
+            if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
+            ntt_st(tile + idx, x);
+        }
+    } else {
+        q = b % a.Q;
+        k1base = (b / a.Q) << logT;
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t i = idx & (M - 1), t = idx >> k;
+            const uint64_t g = ((k1base + t) * a.Q + q) * M + i;
+            Fr x = ntt_ld(a.in + g);
+            if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
+            ntt_st(tile + ((i << logT) + t), x);
+        }
+    }
+    __syncthreads();
+
+    // k radix-2 DIF stages, natural order in, bit-reversed order out (within the tile)
+    const uint32_t nb = E >> 1;
+    for (uint32_t s = 0; s < k; ++s) {
+        const uint32_t lh = k - 1 - s;  // log2(half)
+        const uint32_t half = 1u << lh;
+        for (uint32_t qq = tid; qq < nb; qq += NTT_THREADS) {
+            const uint32_t t = qq & (T - 1), j = qq >> logT;
+            const uint32_t pos = j & (half - 1);
+            const uint32_t i0 = ((j >> lh) << (lh + 1)) + pos;
+            Fr* pa = tile + ((i0 << logT) + t);
+            Fr* pb = tile + (((i0 + half) << logT) + t);
+            const Fr x = ntt_ld(pa), y = ntt_ld(pb);
+            const Fr w = ntt_ld(stw + (pos << s));
+            ntt_st(pa, fe_add(x, y));
+            ntt_st(pb, fe_mul(fe_sub(x, y), w));
+        }
+        __syncthreads();
+    }
+
+    if (!a.last) {
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t t = idx & (T - 1), kk = idx >> logT;
+            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
+            Fr x = ntt_ld(tile + ((src << logT) + t));
+            const uint64_t e = (c0 + t) * (uint64_t)kk;
+            x = fe_mul(x, ntt_pow2l(a.tw_lo, a.tw_hi, a.tw_h, e));
+            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), x);
+        }
+    } else {
+        const uint64_t qrev = (q / a.N3) + a.N2 * (q % a.N3);
+        const uint64_t obase = k1base + a.N1 * qrev;
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t t = idx & (T - 1), kk = idx >> logT;
+            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
+            Fr x = ntt_ld(tile + ((src << logT) + t));
+            const uint64_t o = obase + t + a.out_stride * kk;
+            if (a.post_lo) x = fe_mul(x, ntt_pow2l(a.post_lo, a.post_hi, a.post_h, o));
+            if (a.scale) x = fe_mul(x, ntt_ld(a.scale));
+            ntt_st(a.out + o, x);
+        }
+    }
+}
+
+}  // namespace ty
