@@ -57,6 +57,11 @@ int typlonk_sync(typlonk_ctx* ctx);
 /* ---- SRS: the fixed MSM base vector ([s^i]G, affine), uploaded once per circuit ---------------- */
 /* xy: len*12 limbs; inf: len flag bytes or NULL (= no identity points).  Returns a handle id. */
 int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t len, uint32_t* srs_id);
+/* Build g1[i] = [secret^(start+i)] G, i < len, on the device (Srs::from_secret, kzg/src/srs.rs:15-34;
+ * `start` lets each GPU create only its shard).  secret: 4 limbs (Montgomery).  Setup-time only. */
+int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t start, size_t len, uint32_t* srs_id);
+/* Copy `count` points starting at `offset` back to the host (xy: count*12 limbs; inf: count or NULL). */
+int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_t count, uint64_t* xy, uint8_t* inf);
 int typlonk_srs_free(typlonk_ctx* ctx, uint32_t srs_id);
 int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
 

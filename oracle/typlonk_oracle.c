@@ -1,0 +1,378 @@
+/* typlonk_oracle.c -- CPU restatement of the reference's MSM + NTT path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (typlonk_amd/) never does.  Plain C11, single-threaded like the reference (no rayon in
+ * /root/reference/Cargo.lock; arkworks `parallel`/`asm` features off, kzg/Cargo.toml:9-13).
+ *
+ * What is restated (the algorithm lives in un-vendored crates -- ark-ff / ark-ec / ark-poly 0.3.0,
+ * pins /root/reference/Cargo.lock:28-29, 42-43, 82-83 -- so their published algorithms are
+ * restated and anchored on the reference's call sites):
+ *   oracle_msm_reference   KzgScheme::evaluate_in_s        /root/reference/kzg/src/lib.rs:41-54
+ *                          per term: Fr::into_repr (Montgomery reduce), AffineCurve::mul = MSB-first
+ *                          double-and-add skipping leading zeros with Jacobian double_in_place /
+ *                          add_assign_mixed, `.into()` = Jacobian -> affine (one inversion); then
+ *                          Sum<GroupAffine> = fold of mixed adds from zero, one final inversion.
+ *   oracle_srs_from_secret Srs::g1                          /root/reference/kzg/src/srs.rs:15-24
+ *   oracle_ntt             Radix2EvaluationDomain fft/ifft  call sites plonk/src/proof.rs:50,115
+ *                          radix-2 DIF butterflies + bit reversal; ifft multiplies by size_inv.
+ *   oracle_poly_eval       DensePolynomial::evaluate        kzg/src/lib.rs:57 (Horner)
+ *
+ * PARITY PINNING: pinned against the reference's own test identities (kzg `commit` and
+ * `scalar_mul`, plonk utils `l0`) and the committed Python big-int fixtures in tests/golden/.
+ * The reference cannot be compiled here (no Rust toolchain), so no vector produced by running it
+ * exists: beyond those identities parity is UNPINNED.
+ *
+ * Layout at this ABI = arkworks in-memory form: Fr 4 x u64, Fq 6 x u64, little-endian Montgomery
+ * limbs; G1 = x || y (12 x u64) + separate infinity flag; identity = (0, 1, inf).
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* ---------------------------------------------------------------- Fq: 6 x 64 Montgomery (R = 2^384) */
+#define QN 6
+static const uint64_t Q_MOD[QN] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
+                                   0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
+static const uint64_t Q_ONE[QN] = {0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x5f48985753c758baULL,
+                                   0x77ce585370525745ULL, 0x5c071a97a256ec6dULL, 0x15f65ec3fa80e493ULL};
+static const uint64_t Q_INV = 0x89f3fffcfffcfffdULL; /* -p^-1 mod 2^64 */
+
+typedef struct { uint64_t v[QN]; } fq;
+
+static int fq_is_zero(const fq* a) { uint64_t o = 0; for (int i = 0; i < QN; ++i) o |= a->v[i]; return o == 0; }
+static int fq_eq(const fq* a, const fq* b) { uint64_t o = 0; for (int i = 0; i < QN; ++i) o |= a->v[i] ^ b->v[i]; return o == 0; }
+static int fq_geq_mod(const uint64_t* a) {
+    for (int i = QN - 1; i >= 0; --i) { if (a[i] > Q_MOD[i]) return 1; if (a[i] < Q_MOD[i]) return 0; }
+    return 1;
+}
+static void fq_sub_mod(uint64_t* a) {
+    uint64_t br = 0;
+    for (int i = 0; i < QN; ++i) { u128 t = (u128)a[i] - Q_MOD[i] - br; a[i] = (uint64_t)t; br = (uint64_t)(t >> 64) & 1; }
+}
+static void fq_add(fq* r, const fq* a, const fq* b) {
+    uint64_t c = 0;
+    for (int i = 0; i < QN; ++i) { u128 t = (u128)a->v[i] + b->v[i] + c; r->v[i] = (uint64_t)t; c = (uint64_t)(t >> 64); }
+    if (fq_geq_mod(r->v)) fq_sub_mod(r->v);
+}
+static void fq_sub(fq* r, const fq* a, const fq* b) {
+    uint64_t br = 0;
+    for (int i = 0; i < QN; ++i) { u128 t = (u128)a->v[i] - b->v[i] - br; r->v[i] = (uint64_t)t; br = (uint64_t)(t >> 64) & 1; }
+    if (br) { uint64_t c = 0; for (int i = 0; i < QN; ++i) { u128 t = (u128)r->v[i] + Q_MOD[i] + c; r->v[i] = (uint64_t)t; c = (uint64_t)(t >> 64); } }
+}
+static void fq_dbl(fq* r, const fq* a) { fq_add(r, a, a); }
+static void fq_mul(fq* r, const fq* a, const fq* b) {
+    uint64_t t[QN + 2] = {0};
+    for (int i = 0; i < QN; ++i) {
+        uint64_t c = 0;
+        for (int j = 0; j < QN; ++j) { u128 x = (u128)a->v[j] * b->v[i] + t[j] + c; t[j] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+        u128 s = (u128)t[QN] + c; t[QN] = (uint64_t)s; t[QN + 1] = (uint64_t)(s >> 64);
+        uint64_t m = t[0] * Q_INV;
+        u128 x = (u128)m * Q_MOD[0] + t[0]; c = (uint64_t)(x >> 64);
+        for (int j = 1; j < QN; ++j) { x = (u128)m * Q_MOD[j] + t[j] + c; t[j - 1] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+        s = (u128)t[QN] + c; t[QN - 1] = (uint64_t)s; t[QN] = t[QN + 1] + (uint64_t)(s >> 64);
+    }
+    memcpy(r->v, t, sizeof(r->v));
+    if (t[QN] || fq_geq_mod(r->v)) fq_sub_mod(r->v);
+}
+static void fq_sqr(fq* r, const fq* a) { fq_mul(r, a, a); }
+static void fq_inv(fq* r, const fq* a) { /* a^(p-2); ark-ff uses a binary EEA -- same value */
+    uint64_t e[QN]; memcpy(e, Q_MOD, sizeof(e)); e[0] -= 2; /* low limb ...aaab - 2, no borrow */
+    fq acc; memcpy(acc.v, Q_ONE, sizeof(acc.v));
+    for (int w = QN - 1; w >= 0; --w)
+        for (int b = 63; b >= 0; --b) { fq_sqr(&acc, &acc); if ((e[w] >> b) & 1) fq_mul(&acc, &acc, a); }
+    *r = acc;
+}
+
+/* ---------------------------------------------------------------- Fr: 4 x 64 Montgomery (R = 2^256) */
+#define RN 4
+static const uint64_t R_MOD[RN] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+static const uint64_t R_ONE[RN] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};
+static const uint64_t R_R2[RN] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+static const uint64_t R_INV = 0xfffffffeffffffffULL;
+/* ark-bls12-381 FrParameters::TWO_ADIC_ROOT_OF_UNITY = 7^((r-1)/2^32), canonical integer */
+static const uint64_t R_ROOT_CANON[RN] = {0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL};
+
+typedef struct { uint64_t v[RN]; } fr;
+
+static int fr_geq_mod(const uint64_t* a) {
+    for (int i = RN - 1; i >= 0; --i) { if (a[i] > R_MOD[i]) return 1; if (a[i] < R_MOD[i]) return 0; }
+    return 1;
+}
+static void fr_sub_mod(uint64_t* a) {
+    uint64_t br = 0;
+    for (int i = 0; i < RN; ++i) { u128 t = (u128)a[i] - R_MOD[i] - br; a[i] = (uint64_t)t; br = (uint64_t)(t >> 64) & 1; }
+}
+static void fr_add(fr* r, const fr* a, const fr* b) {
+    uint64_t c = 0;
+    for (int i = 0; i < RN; ++i) { u128 t = (u128)a->v[i] + b->v[i] + c; r->v[i] = (uint64_t)t; c = (uint64_t)(t >> 64); }
+    if (fr_geq_mod(r->v)) fr_sub_mod(r->v);
+}
+static void fr_sub(fr* r, const fr* a, const fr* b) {
+    uint64_t br = 0;
+    for (int i = 0; i < RN; ++i) { u128 t = (u128)a->v[i] - b->v[i] - br; r->v[i] = (uint64_t)t; br = (uint64_t)(t >> 64) & 1; }
+    if (br) { uint64_t c = 0; for (int i = 0; i < RN; ++i) { u128 t = (u128)r->v[i] + R_MOD[i] + c; r->v[i] = (uint64_t)t; c = (uint64_t)(t >> 64); } }
+}
+static void fr_mul(fr* r, const fr* a, const fr* b) {
+    uint64_t t[RN + 2] = {0};
+    for (int i = 0; i < RN; ++i) {
+        uint64_t c = 0;
+        for (int j = 0; j < RN; ++j) { u128 x = (u128)a->v[j] * b->v[i] + t[j] + c; t[j] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+        u128 s = (u128)t[RN] + c; t[RN] = (uint64_t)s; t[RN + 1] = (uint64_t)(s >> 64);
+        uint64_t m = t[0] * R_INV;
+        u128 x = (u128)m * R_MOD[0] + t[0]; c = (uint64_t)(x >> 64);
+        for (int j = 1; j < RN; ++j) { x = (u128)m * R_MOD[j] + t[j] + c; t[j - 1] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+        s = (u128)t[RN] + c; t[RN - 1] = (uint64_t)s; t[RN] = t[RN + 1] + (uint64_t)(s >> 64);
+    }
+    memcpy(r->v, t, sizeof(r->v));
+    if (t[RN] || fr_geq_mod(r->v)) fr_sub_mod(r->v);
+}
+static void fr_from_mont(uint64_t out[RN], const fr* a) { /* into_repr */
+    fr one = {{1, 0, 0, 0}}, t; fr_mul(&t, a, &one); memcpy(out, t.v, sizeof(t.v));
+}
+static void fr_to_mont(fr* r, const uint64_t in[RN]) { fr a, r2; memcpy(a.v, in, sizeof(a.v)); memcpy(r2.v, R_R2, sizeof(r2.v)); fr_mul(r, &a, &r2); }
+static void fr_pow_u64(fr* r, const fr* a, uint64_t e) {
+    fr acc; memcpy(acc.v, R_ONE, sizeof(acc.v));
+    for (int b = 63; b >= 0; --b) { fr_mul(&acc, &acc, &acc); if ((e >> b) & 1) fr_mul(&acc, &acc, a); }
+    *r = acc;
+}
+static void fr_inv(fr* r, const fr* a) {
+    uint64_t e[RN]; memcpy(e, R_MOD, sizeof(e)); e[0] -= 2;
+    fr acc; memcpy(acc.v, R_ONE, sizeof(acc.v));
+    for (int w = RN - 1; w >= 0; --w)
+        for (int b = 63; b >= 0; --b) { fr_mul(&acc, &acc, &acc); if ((e[w] >> b) & 1) fr_mul(&acc, &acc, a); }
+    *r = acc;
+}
+
+/* ---------------------------------------------------------------- G1 Jacobian (ark-ec 0.3.0 short Weierstrass, a = 0) */
+typedef struct { fq x, y, z; } g1j;      /* zero <=> z == 0 */
+typedef struct { fq x, y; int inf; } g1a;
+
+static uint64_t g_group_ops = 0; /* doublings + mixed adds executed (for the CPU baseline's G1-adds/s) */
+uint64_t oracle_group_ops(void) { return g_group_ops; }
+void oracle_group_ops_reset(void) { g_group_ops = 0; }
+
+static void g1j_zero(g1j* p) { memset(p, 0, sizeof(*p)); memcpy(p->x.v, Q_ONE, sizeof(p->x.v)); memcpy(p->y.v, Q_ONE, sizeof(p->y.v)); }
+static int g1j_is_zero(const g1j* p) { return fq_is_zero(&p->z); }
+
+/* double_in_place, dbl-2009-l */
+static void g1j_double(g1j* p) {
+    if (g1j_is_zero(p)) return;
+    ++g_group_ops;
+    fq a, b, c, d, e, f, t;
+    fq_sqr(&a, &p->x); fq_sqr(&b, &p->y); fq_sqr(&c, &b);
+    fq_add(&t, &p->x, &b); fq_sqr(&t, &t); fq_sub(&t, &t, &a); fq_sub(&t, &t, &c); fq_dbl(&d, &t);
+    fq_dbl(&e, &a); fq_add(&e, &e, &a);
+    fq_sqr(&f, &e);
+    fq_mul(&t, &p->y, &p->z); fq_dbl(&p->z, &t);
+    fq_dbl(&t, &d); fq_sub(&p->x, &f, &t);
+    fq_sub(&t, &d, &p->x); fq_mul(&t, &e, &t);
+    fq_dbl(&c, &c); fq_dbl(&c, &c); fq_dbl(&c, &c);
+    fq_sub(&p->y, &t, &c);
+}
+/* add_assign_mixed, madd-2007-bl */
+static void g1j_add_mixed(g1j* p, const g1a* q) {
+    if (q->inf) return;
+    if (g1j_is_zero(p)) { p->x = q->x; p->y = q->y; memcpy(p->z.v, Q_ONE, sizeof(p->z.v)); return; }
+    ++g_group_ops;
+    fq z1z1, u2, s2, h, hh, i, j, r, v, t;
+    fq_sqr(&z1z1, &p->z); fq_mul(&u2, &q->x, &z1z1);
+    fq_mul(&s2, &q->y, &p->z); fq_mul(&s2, &s2, &z1z1);
+    if (fq_eq(&p->x, &u2) && fq_eq(&p->y, &s2)) { g1j_double(p); return; }
+    fq_sub(&h, &u2, &p->x); fq_sqr(&hh, &h);
+    fq_dbl(&i, &hh); fq_dbl(&i, &i);
+    fq_mul(&j, &h, &i);
+    fq_sub(&r, &s2, &p->y); fq_dbl(&r, &r);
+    fq_mul(&v, &p->x, &i);
+    fq x3; fq_sqr(&x3, &r); fq_sub(&x3, &x3, &j); fq_dbl(&t, &v); fq_sub(&x3, &x3, &t);
+    fq y3; fq_sub(&t, &v, &x3); fq_mul(&y3, &r, &t); fq_mul(&t, &p->y, &j); fq_dbl(&t, &t); fq_sub(&y3, &y3, &t);
+    fq z3; fq_add(&z3, &p->z, &h); fq_sqr(&z3, &z3); fq_sub(&z3, &z3, &z1z1); fq_sub(&z3, &z3, &hh);
+    p->x = x3; p->y = y3; p->z = z3;
+}
+/* From<GroupProjective> for GroupAffine */
+static void g1j_to_affine(g1a* out, const g1j* p) {
+    if (g1j_is_zero(p)) { memset(out, 0, sizeof(*out)); memcpy(out->y.v, Q_ONE, sizeof(out->y.v)); out->inf = 1; return; }
+    fq zi, zi2;
+    fq_inv(&zi, &p->z); fq_sqr(&zi2, &zi);
+    fq_mul(&out->x, &p->x, &zi2);
+    fq_mul(&out->y, &p->y, &zi2); fq_mul(&out->y, &out->y, &zi);
+    out->inf = 0;
+}
+/* AffineCurve::mul -> mul_bits(BitIteratorBE(scalar repr)): skip leading zeros, double, add if set */
+static void g1a_mul(g1j* out, const g1a* base, const uint64_t k[RN]) {
+    g1j_zero(out);
+    int started = 0;
+    for (int w = RN - 1; w >= 0; --w)
+        for (int b = 63; b >= 0; --b) {
+            int bit = (int)((k[w] >> b) & 1);
+            if (!started && !bit) continue;
+            started = 1;
+            g1j_double(out);
+            if (bit) g1j_add_mixed(out, base);
+        }
+}
+static void g1a_load(g1a* p, const uint64_t* xy, int inf) { memcpy(p->x.v, xy, 48); memcpy(p->y.v, xy + 6, 48); p->inf = inf; }
+static void g1a_store(uint64_t* xy, uint8_t* inf, const g1a* p) { memcpy(xy, p->x.v, 48); memcpy(xy + 6, p->y.v, 48); *inf = (uint8_t)p->inf; }
+
+/* ================================================================ exported functions */
+
+/* evaluate_in_s, kzg/src/lib.rs:41-54.  Returns -1 for m > len (the assert! at :43). */
+int oracle_msm_reference(const uint64_t* scalars, const uint64_t* points_xy, const uint8_t* points_inf,
+                         size_t m, size_t srs_len, uint64_t out_xy[12], uint8_t* out_inf) {
+    if (m > srs_len) return -1;
+    g1j sum; g1j_zero(&sum);
+    for (size_t i = 0; i < m; ++i) {                         /* poly.zip(srs) */
+        fr s; memcpy(s.v, scalars + 4 * i, 32);
+        uint64_t k[RN]; fr_from_mont(k, &s);                 /* cof.into_repr() inside mul */
+        g1a base; g1a_load(&base, points_xy + 12 * i, points_inf ? points_inf[i] : 0);
+        g1j d; g1a_mul(&d, &base, k);                        /* s.mul(cof)              :49 */
+        g1a da; g1j_to_affine(&da, &d);                      /* d.into()                :50 */
+        g1j_add_mixed(&sum, &da);                            /* .sum()                  :52 */
+    }
+    g1a res; g1j_to_affine(&res, &sum);
+    g1a_store(out_xy, out_inf, &res);
+    return 0;
+}
+
+/* Srs::g1, kzg/src/srs.rs:15-24: [G, sG, s^2 G, ...], one scalar mul + affine conversion each. */
+static const uint64_t G1_X[QN] = {0x5cb38790fd530c16ULL, 0x7817fc679976fff5ULL, 0x154f95c7143ba1c1ULL,
+                                  0xf0ae6acdf3d0e747ULL, 0xedce6ecc21dbf440ULL, 0x120177419e0bfb75ULL};
+static const uint64_t G1_Y[QN] = {0xbaac93d50ce72271ULL, 0x8c22631a7918fd8eULL, 0xdd595f13570725ceULL,
+                                  0x51ac582950405194ULL, 0x0e1c8c3fad0059c0ULL, 0x0bbc3efc5008a26aULL};
+
+int oracle_srs_from_secret(const uint64_t s_mont[4], size_t length, uint64_t* out_xy, uint8_t* out_inf) {
+    g1a gen; memcpy(gen.x.v, G1_X, 48); memcpy(gen.y.v, G1_Y, 48); gen.inf = 0;
+    fr s, sx; memcpy(s.v, s_mont, 32); sx = s;
+    for (size_t i = 0; i < length; ++i) {
+        if (i == 0) { g1a_store(out_xy, out_inf, &gen); continue; }
+        uint64_t k[RN]; fr_from_mont(k, &sx);
+        g1j d; g1a_mul(&d, &gen, k);
+        g1a a; g1j_to_affine(&a, &d);
+        g1a_store(out_xy + 12 * i, out_inf + i, &a);
+        fr_mul(&sx, &sx, &s);
+    }
+    return 0;
+}
+
+/* Test-infrastructure helper (NOT a restatement): the vector [s^i G] for s = 2^log2_s, built as a
+ * chain of Jacobian doublings and batch-normalised with Montgomery's trick, so that 2^20..2^22-point
+ * fixtures take seconds.  Same group elements as oracle_srs_from_secret(s, ...). */
+int oracle_srs_pow2_secret(uint32_t log2_s, size_t length, uint64_t* out_xy, uint8_t* out_inf) {
+    g1a gen; memcpy(gen.x.v, G1_X, 48); memcpy(gen.y.v, G1_Y, 48); gen.inf = 0;
+    const size_t CH = 4096;
+    g1j* js = (g1j*)malloc(CH * sizeof(g1j));
+    fq* pref = (fq*)malloc(CH * sizeof(fq));
+    if (!js || !pref) { free(js); free(pref); return -2; }
+    g1j cur; g1j_zero(&cur); g1j_add_mixed(&cur, &gen);
+    size_t done = 0;
+    while (done < length) {
+        size_t n = length - done < CH ? length - done : CH;
+        for (size_t i = 0; i < n; ++i) {
+            js[i] = cur;
+            for (uint32_t d = 0; d < log2_s; ++d) g1j_double(&cur);
+        }
+        fq run; memcpy(run.v, Q_ONE, 48);
+        for (size_t i = 0; i < n; ++i) { pref[i] = run; fq_mul(&run, &run, &js[i].z); }
+        fq inv; fq_inv(&inv, &run);
+        for (size_t ii = n; ii-- > 0;) {
+            g1a a; fq zi, zi2;
+            fq_mul(&zi, &inv, &pref[ii]); fq_mul(&inv, &inv, &js[ii].z);
+            fq_sqr(&zi2, &zi); fq_mul(&a.x, &js[ii].x, &zi2); fq_mul(&a.y, &js[ii].y, &zi2); fq_mul(&a.y, &a.y, &zi); a.inf = 0;
+            g1a_store(out_xy + 12 * (done + ii), out_inf + done + ii, &a);
+        }
+        done += n;
+    }
+    free(js); free(pref);
+    return 0;
+}
+
+/* k * G as canonical affine (for the commit(p) == [p(s)]G identity at large sizes) */
+int oracle_g1_mul_generator(const uint64_t k_mont[4], uint64_t out_xy[12], uint8_t* out_inf) {
+    g1a gen; memcpy(gen.x.v, G1_X, 48); memcpy(gen.y.v, G1_Y, 48); gen.inf = 0;
+    fr s; memcpy(s.v, k_mont, 32);
+    uint64_t k[RN]; fr_from_mont(k, &s);
+    g1j d; g1a_mul(&d, &gen, k);
+    g1a a; g1j_to_affine(&a, &d);
+    g1a_store(out_xy, out_inf, &a);
+    return 0;
+}
+
+/* DensePolynomial::evaluate (Horner), kzg/src/lib.rs:57 */
+int oracle_poly_eval(const uint64_t* coeffs, size_t n, const uint64_t x_mont[4], uint64_t out[4]) {
+    fr acc = {{0, 0, 0, 0}}, x; memcpy(x.v, x_mont, 32);
+    for (size_t i = n; i-- > 0;) { fr c; memcpy(c.v, coeffs + 4 * i, 32); fr_mul(&acc, &acc, &x); fr_add(&acc, &acc, &c); }
+    memcpy(out, acc.v, 32);
+    return 0;
+}
+
+/* (p(X) - p(z)) / (X - z): the division at kzg/src/lib.rs:58-61.  q has n-1 coefficients. */
+int oracle_poly_div_linear(const uint64_t* coeffs, size_t n, const uint64_t z_mont[4], uint64_t* q, uint64_t y[4]) {
+    fr z; memcpy(z.v, z_mont, 32);
+    fr carry = {{0, 0, 0, 0}};
+    for (size_t i = n; i-- > 1;) {
+        fr c; memcpy(c.v, coeffs + 4 * i, 32);
+        fr_mul(&carry, &carry, &z); fr_add(&carry, &carry, &c);
+        memcpy(q + 4 * (i - 1), carry.v, 32);
+    }
+    if (n) { fr c; memcpy(c.v, coeffs, 32); fr_mul(&carry, &carry, &z); fr_add(&carry, &carry, &c); }
+    memcpy(y, carry.v, 32);
+    return 0;
+}
+
+/* Radix2EvaluationDomain::{fft, ifft} (+ coset variants), natural order in and out.
+ * Returns -3 for log_n > 32 (GeneralEvaluationDomain::new returns None -> unwrap() panic). */
+int oracle_ntt(uint64_t* data, uint32_t log_n, int inverse, const uint64_t* coset_mont) {
+    if (log_n > 32) return -3;
+    const size_t n = (size_t)1 << log_n;
+    fr* a = (fr*)data;
+    fr root; fr_to_mont(&root, R_ROOT_CANON);
+    for (uint32_t i = log_n; i < 32; ++i) fr_mul(&root, &root, &root);   /* group_gen */
+    if (inverse) fr_inv(&root, &root);                                      /* group_gen_inv */
+    if (!inverse && coset_mont) {                                           /* coset_fft: scale by g^i first */
+        fr g, x; memcpy(g.v, coset_mont, 32); memcpy(x.v, R_ONE, 32);
+        for (size_t i = 0; i < n; ++i) { fr_mul(&a[i], &a[i], &x); fr_mul(&x, &x, &g); }
+    }
+    /* roots table w^j, j < n/2 */
+    size_t half = n / 2;
+    fr* tw = (fr*)malloc((half ? half : 1) * sizeof(fr));
+    if (!tw) return -2;
+    { fr x; memcpy(x.v, R_ONE, 32); for (size_t j = 0; j < half; ++j) { tw[j] = x; fr_mul(&x, &x, &root); } }
+    /* DIF: input in order, output bit-reversed */
+    size_t gap = half, step = 1;
+    while (gap > 0) {
+        for (size_t start = 0; start < n; start += 2 * gap)
+            for (size_t j = 0; j < gap; ++j) {
+                fr u = a[start + j], v = a[start + j + gap], d;
+                fr_add(&a[start + j], &u, &v);
+                fr_sub(&d, &u, &v);
+                fr_mul(&a[start + j + gap], &d, &tw[j * step]);
+            }
+        gap >>= 1; step <<= 1;
+    }
+    /* derange (bit reversal) */
+    for (size_t i = 0; i < n; ++i) {
+        size_t r = 0;
+        for (uint32_t b = 0; b < log_n; ++b) r |= ((i >> b) & 1) << (log_n - 1 - b);
+        if (i < r) { fr t = a[i]; a[i] = a[r]; a[r] = t; }
+    }
+    free(tw);
+    if (inverse) {
+        fr nn = {{(uint64_t)n, 0, 0, 0}}, nm, ninv; fr_to_mont(&nm, nn.v); fr_inv(&ninv, &nm);   /* size_inv */
+        if (coset_mont) {
+            fr g, gi, x = ninv; memcpy(g.v, coset_mont, 32); fr_inv(&gi, &g);
+            for (size_t i = 0; i < n; ++i) { fr_mul(&a[i], &a[i], &x); fr_mul(&x, &x, &gi); }
+        } else {
+            for (size_t i = 0; i < n; ++i) fr_mul(&a[i], &a[i], &ninv);
+        }
+    }
+    (void)fr_pow_u64;
+    return 0;
+}
+
+/* a[i] * b[i] and a[i] + b[i] helpers for property tests at full size */
+int oracle_fr_vec_add(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    for (size_t i = 0; i < n; ++i) fr_add((fr*)(out + 4 * i), (const fr*)(a + 4 * i), (const fr*)(b + 4 * i));
+    return 0;
+}

@@ -42,3 +42,13 @@ def g1_unpack_one(xy, inf):
 
 def u32p(a: np.ndarray):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+
+
+def load_golden(name):
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+        return json.load(f)
+
+
+def hex_pt(p):
+    return None if p is None else (int(p[0], 16), int(p[1], 16))

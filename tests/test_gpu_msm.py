@@ -146,3 +146,58 @@ def test_device_resident_intt_then_msm(ctx):
     assert g1_unpack_one(out, inf) == commit_identity(coeffs, 2)
     buf.free()
     ctx.srs_free(sid)
+
+
+def test_srs_generate_matches_reference_faithful_generator(ctx):
+    """typlonk_srs_generate == Srs::from_secret (kzg/src/srs.rs:15-34) restated by the C oracle,
+    including a shard that starts at a non-zero power."""
+    from oracle import coracle as CO
+
+    s = 0x0123456789ABCDEF0123456789ABCDEF
+    s_limbs = np.array(O.fr_to_mont_limbs(s), dtype=np.uint64)
+    ref_xy, ref_inf = CO.srs_from_secret(s_limbs, 40)
+    sid = ctx.srs_generate(s_limbs, 40)
+    xy, inf = ctx.srs_download(sid)
+    assert (xy == ref_xy).all() and (inf == ref_inf).all()
+    ctx.srs_free(sid)
+    sid = ctx.srs_generate(s_limbs, 15, start=25)
+    xy, inf = ctx.srs_download(sid)
+    assert (xy == ref_xy[25:]).all()
+    ctx.srs_free(sid)
+    # s = 0 -> [G, inf, inf, ...]
+    sid = ctx.srs_generate(np.zeros(4, dtype=np.uint64), 4)
+    xy, inf = ctx.srs_download(sid)
+    assert list(inf) == [0, 1, 1, 1] and g1_unpack_one(xy[0], 0) == O.G1
+    assert not xy[1, :6].any() and [int(x) for x in xy[1, 6:]] == O.fq_to_mont_limbs(1)
+    ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("log_m,delta", [(16, 0), (16, -1), (20, 0), (20, -3)])
+def test_commit_identity_large(ctx, log_m, delta):
+    """BASELINE configs 2-3 sizes (and the n-1 / n-3 lengths prove() uses): commit(p) == [p(s)]G,
+    s = 2, SRS generated on the device, checked with the C oracle's Horner + scalar mul."""
+    from oracle import coracle as CO
+
+    n = 1 << log_m
+    m = n + delta
+    s_limbs = np.array(O.fr_to_mont_limbs(2), dtype=np.uint64)
+    sid = ctx.srs_generate(s_limbs, n + 3)
+    rng = np.random.default_rng(log_m)
+    sc = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(m, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    out, inf = ctx.msm(sid, sc)
+    exp, einf = CO.g1_mul_generator(CO.poly_eval(sc, s_limbs))
+    assert (out == exp).all() and inf == einf
+    ctx.srs_free(sid)
+
+
+def test_golden_msm_fixtures(ctx):
+    from helpers import hex_pt, load_golden
+
+    for case in load_golden("msm.json"):
+        s, n = int(case["secret"], 16), case["srs_len"]
+        sc = [int(x, 16) for x in case["scalars"]]
+        sid = ctx.srs_generate(np.array(O.fr_to_mont_limbs(s), dtype=np.uint64), n)
+        out, inf = ctx.msm(sid, fr_pack(sc) if sc else np.zeros((0, 4), dtype=np.uint64), len(sc))
+        assert g1_unpack_one(out, inf) == hex_pt(case["expected"])
+        ctx.srs_free(sid)

@@ -109,3 +109,28 @@ def test_errors(ctx):
     with pytest.raises(TyplonkError) as e:
         ctx.ntt_devptr(1, 33)
     assert e.value.code == ERR_DOMAIN
+
+
+def test_golden_ntt_fixtures(ctx):
+    from helpers import load_golden
+
+    g = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
+    for case in load_golden("ntt.json"):
+        L = case["log_n"]
+        v = fr_pack([int(x, 16) for x in case["input"]])
+        assert fr_unpack(ctx.ntt(v, L)) == [int(x, 16) for x in case["forward"]]
+        assert fr_unpack(ctx.ntt(v, L, inverse=True)) == [int(x, 16) for x in case["inverse"]]
+        assert fr_unpack(ctx.ntt(v, L, coset=g)) == [int(x, 16) for x in case["coset7_forward"]]
+        assert fr_unpack(ctx.ntt(v, L, inverse=True, coset=g)) == [int(x, 16) for x in case["coset7_inverse"]]
+
+
+@pytest.mark.parametrize("log_n", [16, 20, 22])
+def test_full_size_vs_c_oracle(ctx, log_n):
+    """BASELINE config sizes: whole-vector equality with the C restatement of ark-poly's radix-2 FFT"""
+    from oracle import coracle as CO
+
+    x = rand_limbs(1000 + log_n, 1 << log_n)
+    assert (ctx.ntt(x, log_n) == CO.ntt(x, log_n)).all()
+    g = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
+    if log_n <= 20:
+        assert (ctx.ntt(x, log_n, inverse=True, coset=g) == CO.ntt(x, log_n, inverse=True, coset=g)).all()

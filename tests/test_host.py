@@ -1,0 +1,148 @@
+"""CPU suite for the product's host side: the shared Fp/Fr/G1 arithmetic headers (through the
+host shim), the host-only C-ABI helper, and that the HIP library loads and exports every symbol
+include/typlonk.h declares.  No GPU compute is called."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from helpers import O, ROOT, g1_pack, g1_unpack_one, u32p
+
+
+@pytest.fixture(scope="module")
+def shim(built):
+    return ctypes.CDLL(os.path.join(ROOT, "tests", "cpp", "libff_host_shim.so"))
+
+
+def _fr(x):
+    return np.array(O.fr_to_mont_limbs(x), dtype=np.uint64)
+
+
+def _fq(x):
+    return np.array(O.fq_to_mont_limbs(x), dtype=np.uint64)
+
+
+def _call(shim, fn, n, *args):
+    o = np.zeros(n, dtype=np.uint64)
+    getattr(shim, fn)(*[u32p(a) for a in args], u32p(o))
+    return [int(v) for v in o]
+
+
+def test_field_arithmetic_vs_bigint(shim):
+    rnd = random.Random(1)
+    er = [0, 1, 2, O.R - 1, O.R - 2, (1 << 255) % O.R, (1 << 32) - 1, 1 << 32]
+    ep = [0, 1, 2, O.P - 1, O.P - 2, (1 << 381) % O.P, (1 << 32) - 1]
+    for it in range(600):
+        a = rnd.choice(er) if it < 64 else rnd.randrange(O.R)
+        b = er[it % 8] if it < 64 else rnd.randrange(O.R)
+        assert O.fr_from_mont_limbs(_call(shim, "shim_fr_mul", 4, _fr(a), _fr(b))) == a * b % O.R
+        assert O.fr_from_mont_limbs(_call(shim, "shim_fr_add", 4, _fr(a), _fr(b))) == (a + b) % O.R
+        assert O.fr_from_mont_limbs(_call(shim, "shim_fr_sub", 4, _fr(a), _fr(b))) == (a - b) % O.R
+        x = _call(shim, "shim_fr_from_mont", 4, _fr(a))
+        assert sum(v << (64 * i) for i, v in enumerate(x)) == a
+        a = rnd.choice(ep) if it < 64 else rnd.randrange(O.P)
+        b = ep[it % 7] if it < 64 else rnd.randrange(O.P)
+        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_mul", 6, _fq(a), _fq(b))) == a * b % O.P
+        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_add", 6, _fq(a), _fq(b))) == (a + b) % O.P
+        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_sub", 6, _fq(a), _fq(b))) == (a - b) % O.P
+        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_neg", 6, _fq(a))) == (-a) % O.P
+        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_dbl", 6, _fq(a))) == (2 * a) % O.P
+    for a in [1, 2, 5, rnd.randrange(O.P)]:
+        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_inv", 6, _fq(a))) == pow(a, -1, O.P)
+    for a in [1, 2, 5, rnd.randrange(O.R)]:
+        assert O.fr_from_mont_limbs(_call(shim, "shim_fr_inv", 4, _fr(a))) == pow(a, -1, O.R)
+
+
+def _pt(p):
+    if p is None:
+        return np.zeros(12, dtype=np.uint64)
+    return np.array(O.fq_to_mont_limbs(p[0]) + O.fq_to_mont_limbs(p[1]), dtype=np.uint64)
+
+
+def _unpt(a):
+    a = [int(x) for x in a]
+    if not any(a):
+        return None
+    return (O.fq_from_mont_limbs(a[:6]), O.fq_from_mont_limbs(a[6:]))
+
+
+def test_group_law_all_exceptional_cases(shim):
+    """identity operands, P + P, P + (-P), with and without a non-trivial Z on the accumulator"""
+    rnd = random.Random(2)
+    pts = [None] + [O.g1_mul(O.G1, k) for k in [1, 2, 3, 5, O.R - 1, O.R - 2, 12345678901234567890]]
+    for a in pts:
+        for b in pts:
+            for neg in (0, 1):
+                for zs in (None, _fq(rnd.randrange(1, O.P))):
+                    o = np.zeros(12, dtype=np.uint64)
+                    shim.shim_g1_madd(u32p(_pt(a)), u32p(_pt(b)), neg, None if zs is None else u32p(zs), u32p(o))
+                    exp = O.g1_add(a, O.g1_neg(b) if neg else b)
+                    assert _unpt(o) == exp
+                    if not neg:
+                        z2 = _fq(rnd.randrange(1, O.P))
+                        shim.shim_g1_add(u32p(_pt(a)), u32p(_pt(b)), None if zs is None else u32p(zs), u32p(z2), u32p(o))
+                        assert _unpt(o) == exp
+    for k in [0, 1, 2, 3, 65535, 65536, 0xFFFFFFFF]:
+        o = np.zeros(12, dtype=np.uint64)
+        shim.shim_g1_mul_small(u32p(_pt(pts[3])), k, u32p(o))
+        assert _unpt(o) == O.g1_mul(pts[3], k)
+
+
+def test_library_loads_and_exports_every_declared_symbol(built):
+    import typlonk_amd
+    from typlonk_amd.capi import SYMBOLS
+
+    lib = typlonk_amd.load_library()
+    header = open(os.path.join(ROOT, "include", "typlonk.h")).read()
+    declared = set(re.findall(r"\b(typlonk_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(SYMBOLS), declared ^ set(SYMBOLS)
+    for s in SYMBOLS:
+        assert getattr(lib, s) is not None
+    assert b"gfx950" in lib.typlonk_version()
+    assert lib.typlonk_strerror(-2) == b"MSM length exceeds SRS length"
+
+
+def test_no_cpu_fallback_without_device(built):
+    """the product path must fail loudly when there is no GPU (this suite runs without one)"""
+    import torch
+    import typlonk_amd
+    from typlonk_amd.capi import ERR_NO_DEVICE, TyplonkError
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(TyplonkError) as e:
+        typlonk_amd.Context(0)
+    assert e.value.code == ERR_NO_DEVICE
+
+
+def test_g1_sum_host_fold(built):
+    """deterministic fold of per-rank partial sums (host-only entry point)"""
+    import typlonk_amd
+
+    pts = [O.g1_mul(O.G1, k) for k in (3, 5, 7)] + [None, O.g1_mul(O.G1, O.R - 15)]
+    xy, inf = g1_pack(pts)
+    out, oi = typlonk_amd.g1_sum_host(xy[:3], inf[:3])
+    assert g1_unpack_one(out, oi) == O.g1_mul(O.G1, 15)
+    out, oi = typlonk_amd.g1_sum_host(xy[:4], inf[:4])
+    assert g1_unpack_one(out, oi) == O.g1_mul(O.G1, 15)
+    out, oi = typlonk_amd.g1_sum_host(xy, inf)
+    assert oi == 1 and g1_unpack_one(out, oi) is None
+    assert not out[:6].any() and [int(x) for x in out[6:]] == O.fq_to_mont_limbs(1)
+    dup = np.stack([xy[0], xy[0]])
+    out, oi = typlonk_amd.g1_sum_host(dup, None)
+    assert g1_unpack_one(out, oi) == O.g1_mul(O.G1, 6)   # P + P goes through the doubling branch
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure: nothing under typlonk_amd/ or include/ may import, link or
+    load it"""
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|liboracle|coracle|bls12_381\.py|oracle/)")
+    for top in ("typlonk_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not pat.search(src), f"{f} references the oracle"

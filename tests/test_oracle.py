@@ -1,0 +1,122 @@
+"""CPU suite: pins both oracles (Python big-int and the C restatement) against the committed
+golden vectors and the reference's own test identities.  No GPU, no HIP compute calls."""
+import numpy as np
+import pytest
+
+from helpers import O, fr_pack, fr_unpack, g1_pack, g1_unpack_one, hex_pt, load_golden
+from oracle import coracle as CO
+
+KAT = load_golden("kat.json")
+G = lambda v: np.array(O.fr_to_mont_limbs(v), dtype=np.uint64)  # noqa: E731
+
+
+def test_public_constants():
+    assert int(KAT["p"], 16) == O.P and int(KAT["r"], 16) == O.R
+    assert O.g1_is_on_curve(O.G1)
+    assert O.g1_mul(O.G1, O.R - 1) == O.g1_neg(O.G1)          # r * G = identity
+    assert pow(O.FR_ROOT_OF_UNITY, 1 << 31, O.R) == O.R - 1   # primitive 2^32-th root
+    assert pow(7, (O.R - 1) >> 32, O.R) == int(KAT["fr_root_of_unity_2_32"], 16)
+    assert [hex(x) for x in O.fq_to_mont_limbs(O.GX)] == KAT["g1_x_mont_limbs"]
+    # literals from SURVEY.md section 8c (arkworks / zkcrypto generator in Montgomery form)
+    assert O.fq_to_mont_limbs(O.GX)[0] == 0x5CB38790FD530C16 and O.fq_to_mont_limbs(O.GY)[5] == 0x0BBC3EFC5008A26A
+    assert O.domain_root(16) == 0x2155379D12180CAA88F39A78F1AEB57867A665AE1FCADC91D7118F85CD96B8AD
+
+
+def test_reference_commit_test_python():
+    """kzg/src/lib.rs:95-109"""
+    srs = O.srs_from_secret(2, 10)
+    assert len(srs) == 13
+    c = O.kzg_commit(srs, [1, 2, 3])
+    assert c == O.g1_mul(O.G1, O.poly_eval([1, 2, 3], 2)) == hex_pt(KAT["commit_1_2_3_s2"])
+    assert c[0] == 0x1098F178F84FC753A76BB63709E9BE91EEC3FF5F7F3A5F4836F34FE8A1A6D6C5578D8FD820573CEF3A01E2BFEF3EAF3A
+    assert O.poly_eval([1, 2, 3], 1) == 6
+    w, y = O.kzg_open(srs, [1, 2, 3], 1)
+    assert y == 6 and w == hex_pt(KAT["open_1_2_3_s2_z1"]["w"]) == O.g1_mul(O.G1, 11)
+    # trapdoor form of the pairing check e(W, [s - z]) == e(C - yG, G2): (s - z) W == C - y G
+    assert O.g1_mul(w, 2 - 1) == O.g1_add(c, O.g1_neg(O.g1_mul(O.G1, y)))
+
+
+def test_reference_commit_test_c():
+    xy, inf = CO.srs_from_secret(G(2), 13)
+    assert [g1_unpack_one(xy[i], inf[i]) for i in range(13)] == O.srs_from_secret(2, 10)
+    out, oi = CO.msm_reference(fr_pack([1, 2, 3]), xy, inf)
+    assert g1_unpack_one(out, oi) == hex_pt(KAT["commit_1_2_3_s2"])
+    q, y = CO.poly_div_linear(fr_pack([1, 2, 3]), G(1))
+    assert fr_unpack(y) == [6] and fr_unpack(q) == [5, 3]
+    out, oi = CO.msm_reference(q, xy, inf)
+    assert g1_unpack_one(out, oi) == hex_pt(KAT["open_1_2_3_s2_z1"]["w"])
+    with pytest.raises(AssertionError):   # assert!(srs.len() > polynomial.degree())
+        CO.msm_reference(fr_pack([1] * 14), xy, inf)
+
+
+def test_reference_scalar_mul_test():
+    """kzg/src/lib.rs:160-171: commit(9 p) == 9 commit(p)"""
+    xy, inf = CO.srs_from_secret(G(0xABCDEF0123), 8)
+    p = O.random_frs(21, 5)
+    a, ai = CO.msm_reference(fr_pack([9 * c % O.R for c in p]), xy, inf)
+    b, bi = CO.msm_reference(fr_pack(p), xy, inf)
+    assert g1_unpack_one(a, ai) == O.g1_mul(g1_unpack_one(b, bi), 9)
+
+
+def test_golden_msm_both_oracles():
+    for case in load_golden("msm.json"):
+        s, n = int(case["secret"], 16), case["srs_len"]
+        sc = [int(x, 16) for x in case["scalars"]]
+        exp = hex_pt(case["expected"])
+        srs = O.srs_from_secret_fast(s, n)
+        assert O.msm_naive(sc, srs) == exp
+        xy, inf = g1_pack(srs)
+        out, oi = CO.msm_reference(fr_pack(sc) if sc else np.zeros((0, 4), dtype=np.uint64), xy, inf)
+        assert g1_unpack_one(out, oi) == exp
+        if exp is None:
+            assert oi == 1 and not out[:6].any() and [int(x) for x in out[6:]] == O.fq_to_mont_limbs(1)
+
+
+def test_golden_ntt_both_oracles():
+    assert [int(x, 16) for x in KAT["ntt4_1_2_3_4"]] == O.ntt([1, 2, 3, 4], 2) == fr_unpack(CO.ntt(fr_pack([1, 2, 3, 4]), 2))
+    for case in load_golden("ntt.json"):
+        L = case["log_n"]
+        v = [int(x, 16) for x in case["input"]]
+        for key, kw in (("forward", {}), ("inverse", {"inverse": True}), ("coset7_forward", {"coset": 7}),
+                        ("coset7_inverse", {"inverse": True, "coset": 7})):
+            exp = [int(x, 16) for x in case[key]]
+            assert O.ntt(v, L, **kw) == exp
+            ckw = {"inverse": kw.get("inverse", False), "coset": G(7) if "coset" in kw else None}
+            assert fr_unpack(CO.ntt(fr_pack(v), L, **ckw)) == exp
+
+
+def test_reference_l0_test_c_oracle():
+    """plonk/src/utils.rs:161-177 at the reference's own size N = 2^16"""
+    n = 1 << 16
+    coeffs = np.tile(G(pow(n, -1, O.R)), (n, 1))
+    ev = CO.ntt(coeffs, 16)
+    assert (ev[0] == G(1)).all() and not ev[1:].any()
+
+
+def test_c_oracle_ntt_roundtrip_and_domain_error():
+    v = fr_pack(O.random_frs(5, 1 << 12))
+    assert (CO.ntt(CO.ntt(v, 12), 12, inverse=True) == v).all()
+    assert (CO.ntt(CO.ntt(v, 12, coset=G(7)), 12, inverse=True, coset=G(7)) == v).all()
+    import ctypes
+    assert CO.lib().oracle_ntt(None, ctypes.c_uint32(33), 0, None) == -3
+
+
+def test_interpolate_trims_and_open_division():
+    """from_coefficients_vec strips trailing zeros (sets MSM lengths); open() divides by X - z."""
+    evals = O.ntt([5, 7, 0, 0], 2)
+    assert O.interpolate(evals, 2) == [5, 7]
+    assert O.interpolate([0, 0, 0, 0], 2) == []
+    p = O.random_frs(31, 9)
+    z = 12345
+    q, y = O.poly_div_linear(p, z)
+    # q(X) (X - z) + y == p(X) at a random point
+    x = 987654321
+    assert (O.poly_eval(q, x) * (x - z) + y) % O.R == O.poly_eval(p, x)
+
+
+def test_srs_generators_agree():
+    xy, inf = CO.srs_pow2_secret(1, 100)
+    xy2, inf2 = CO.srs_from_secret(G(2), 100)
+    assert (xy == xy2).all() and (inf == inf2).all()
+    xy4, _ = CO.srs_pow2_secret(2, 10)
+    assert g1_unpack_one(xy4[9], 0) == O.g1_mul(O.G1, pow(4, 9, O.R))

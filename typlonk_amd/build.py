@@ -2,7 +2,6 @@
 
   typlonk_amd/libtyplonk_hip.so   HIP kernels + C ABI (include/typlonk.h)       -- hipcc
   tests/cpp/libff_host_shim.so    host shim over the shared arithmetic headers  -- g++
-  oracle/liboracle.so             C restatement of the reference path (checker) -- gcc
 
 Every target is rebuilt only when one of its sources is newer than the output.
 """
@@ -36,11 +35,30 @@ def hipcc_path() -> str:
     return p
 
 
+HIP_UNITS = ["capi.hip", "ntt_kernels.hip", "msm_sort.hip", "msm_accum.hip", "msm_reduce.hip", "srs_gen.hip"]
+
+
 def build_hip(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "typlonk.h")]
-    if force or _stale(LIB, srcs):
-        _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-              os.path.join(CSRC, "capi.hip"), "-o", LIB])
+    """one object per .hip unit (compiled in parallel, each only when stale), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hdrs.append(os.path.join(ROOT, "include", "typlonk.h"))
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = hipcc_path()
+    jobs, objs = [], []
+    for u in HIP_UNITS:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(objdir, u.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or not os.path.exists(LIB):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
     return LIB
 
 
@@ -53,20 +71,9 @@ def build_host_shim(force: bool = False) -> str:
     return out
 
 
-def build_oracle(force: bool = False) -> str | None:
-    src = os.path.join(ROOT, "oracle", "typlonk_oracle.c")
-    out = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not os.path.exists(src):
-        return None
-    if force or _stale(out, [src]):
-        _run(["gcc", "-O2", "-std=c11", "-shared", "-fPIC", src, "-o", out])
-    return out
-
-
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_host_shim(force)
-    build_oracle(force)
 
 
 if __name__ == "__main__":

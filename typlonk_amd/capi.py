@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RA
 # every symbol include/typlonk.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
-    "typlonk_sync", "typlonk_srs_load", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
+    "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
     "typlonk_ntt_fr_devptr", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
@@ -55,6 +55,8 @@ def load_library() -> C.CDLL:
     lib.typlonk_set_stream.argtypes = [vp, vp]
     lib.typlonk_sync.argtypes = [vp]
     lib.typlonk_srs_load.argtypes = [vp, u64p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
+    lib.typlonk_srs_generate.argtypes = [vp, u64p, C.c_uint64, C.c_size_t, C.POINTER(C.c_uint32)]
+    lib.typlonk_srs_download.argtypes = [vp, C.c_uint32, C.c_size_t, C.c_size_t, u64p, u8p]
     lib.typlonk_srs_free.argtypes = [vp, C.c_uint32]
     lib.typlonk_srs_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
     lib.typlonk_msm_g1.argtypes = [vp, C.c_uint32, u64p, C.c_size_t, u64p, u8p]
@@ -189,6 +191,20 @@ class Context:
         sid = C.c_uint32()
         self._chk(self.lib.typlonk_srs_load(self.h, _u64p(xy), infp, xy.shape[0], C.byref(sid)))
         return sid.value
+
+    def srs_generate(self, secret_limbs, length: int, start: int = 0) -> int:
+        """[secret^(start+i)] G on the device (Srs::from_secret); secret as 4 Montgomery limbs"""
+        s = np.ascontiguousarray(secret_limbs, dtype=np.uint64).reshape(4)
+        sid = C.c_uint32()
+        self._chk(self.lib.typlonk_srs_generate(self.h, _u64p(s), start, length, C.byref(sid)))
+        return sid.value
+
+    def srs_download(self, sid: int, offset: int = 0, count: int | None = None):
+        count = self.srs_len(sid) - offset if count is None else count
+        xy = np.zeros((count, 12), dtype=np.uint64)
+        inf = np.zeros(count, dtype=np.uint8)
+        self._chk(self.lib.typlonk_srs_download(self.h, sid, offset, count, _u64p(xy), _u8p(inf)))
+        return xy, inf
 
     def srs_free(self, sid: int):
         self._chk(self.lib.typlonk_srs_free(self.h, sid))

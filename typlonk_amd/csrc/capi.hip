@@ -3,8 +3,8 @@
 // final (host) window combine.  There is deliberately no CPU compute fallback: without a HIP
 // device typlonk_init fails with TYPLONK_ERR_NO_DEVICE.
 #include "../../include/typlonk.h"
-#include "msm_kernels.hpp"
-#include "ntt_kernels.hpp"
+#include "g1.hpp"
+#include "launch.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -333,7 +333,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         {
             static const char* names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
             StageTimer st(ctx, names[p]);
-            hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)blocks), dim3(NTT_THREADS), lds, ctx->stream, a);
+            launch_ntt_pass(a, (unsigned)blocks, lds, ctx->stream);
         }
         HIPCHK(hipGetLastError());
         rows *= M;
@@ -420,25 +420,19 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     {
         StageTimer st(ctx, "msm_digits");
         HIPCHK(hipMemsetAsync(counts, 0, nb * 4, s));
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((m + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS),
-                           0, s, d_scalars, (uint64_t)m, c, W, keys, counts);
+        launch_msm_digits(d_scalars, (uint64_t)m, c, W, keys, counts, s);
     }
     {
         StageTimer st(ctx, "msm_scan");
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(scan_blocks), dim3(256), 0, s, counts, nb, blocksums);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, blocksums, scan_blocks);
-        hipLaunchKernelGGL(scan_finish_kernel, dim3(scan_blocks), dim3(256), 0, s, counts, nb, blocksums, offsets,
-                           cursor);
+        launch_scan(counts, nb, blocksums, offsets, cursor, s);
     }
     {
         StageTimer st(ctx, "msm_scatter");
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((total + MSM_THREADS - 1) / MSM_THREADS)),
-                           dim3(MSM_THREADS), 0, s, keys, (uint64_t)m, total, cursor, sorted);
+        launch_msm_scatter(keys, (uint64_t)m, total, cursor, sorted, s);
     }
     {
         StageTimer st(ctx, "msm_accum");
-        hipLaunchKernelGGL(msm_accum_kernel, dim3((unsigned)((nb + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
-                           dim3(MSM_ACC_THREADS), 0, s, srs.d_points, offsets, sorted, (uint32_t)nb, buckets);
+        launch_msm_accum(srs.d_points, offsets, sorted, (uint32_t)nb, buckets, s);
     }
     uint32_t* cur = pa;
     uint32_t* other = pb;
@@ -446,13 +440,12 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     {
         StageTimer st(ctx, "msm_reduce");
         const uint32_t group = std::min<uint32_t>(64, npw);
-        hipLaunchKernelGGL(msm_reduce_kernel, dim3((nodes + 63) / 64), dim3(64), 0, s, buckets, B, L, nodes, group, c,
-                           cur);
+        launch_msm_reduce(buckets, B, L, nodes, group, c, cur, s);
         n_in = npw / group;
         while (n_in > 1) {
             const uint32_t g2 = std::min<uint32_t>(64, n_in);
             const uint32_t tot = W * n_in;
-            hipLaunchKernelGGL(msm_fold_kernel, dim3((tot + 63) / 64), dim3(64), 0, s, cur, tot, g2, other);
+            launch_msm_fold(cur, tot, g2, other, s);
             std::swap(cur, other);
             n_in /= g2;
         }
@@ -557,8 +550,7 @@ int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, s
             uint8_t* d_inf = nullptr;
             HIPCHK(hipMalloc((void**)&d_inf, len));
             HIPCHK(hipMemcpyAsync(d_inf, inf, len, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(msm_mark_inf_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream,
-                               e.d_points, d_inf, (uint64_t)len);
+            launch_mark_inf(e.d_points, d_inf, (uint64_t)len, ctx->stream);
             HIPCHK(hipStreamSynchronize(ctx->stream));
             HIPCHK(hipFree(d_inf));
         }
@@ -585,6 +577,43 @@ int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len) {
     auto it = ctx->srs.find(srs_id);
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
     *len = it->second.len;
+    return TYPLONK_OK;
+}
+
+int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t start, size_t len, uint32_t* srs_id) {
+    if (!ctx || !secret || !srs_id) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    SrsEntry e;
+    e.len = len;
+    HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * 96));
+    if (len) {
+        Fr s;
+        memcpy(s.v, secret, sizeof(s.v));
+        launch_srs_generate(s, start, (uint64_t)len, e.d_points, ctx->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    const uint32_t id = ctx->next_srs++;
+    ctx->srs[id] = e;
+    *srs_id = id;
+    return TYPLONK_OK;
+}
+
+int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_t count, uint64_t* xy, uint8_t* inf) {
+    if (!ctx || (!xy && count)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    if (offset > it->second.len || count > it->second.len - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside SRS");
+    if (!count) return TYPLONK_OK;
+    HIPCHK(hipMemcpyAsync(xy, it->second.d_points + offset * 24, count * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    Fq one = Fq::one();
+    for (size_t i = 0; i < count; ++i) {  // device encoding (0,0) -> ark-ec (0, 1, inf)
+        bool z = true;
+        for (int w = 0; w < 12; ++w) z = z && xy[i * 12 + w] == 0;
+        if (inf) inf[i] = z ? 1 : 0;
+        if (z) memcpy(xy + i * 12 + 6, one.v, sizeof(one.v));
+    }
     return TYPLONK_OK;
 }
 

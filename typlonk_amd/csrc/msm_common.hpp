@@ -1,0 +1,67 @@
+// Pippenger bucket MSM over BLS12-381 G1 (replaces the per-term double-and-add of
+// KzgScheme::evaluate_in_s, /root/reference/kzg/src/lib.rs:41-54).
+//
+//   1. msm_digits_kernel   one thread per scalar: Montgomery -> canonical (ark-ff into_repr, the
+//                          conversion lib.rs:49 performs per term), signed c-bit window slicing,
+//                          one key per (window, scalar) + bucket histogram.
+//   2. scan kernels        exclusive prefix sum of the histogram -> bucket offsets.
+//   3. msm_scatter_kernel  counting sort of (point index, sign) by bucket.
+//   4. msm_accum_kernel    one thread per bucket: XYZZ accumulator in registers, mixed additions of
+//                          the bucket's affine points gathered from the resident SRS.
+//   5. msm_reduce_kernel   per window sum_k k*B_k: 8-bucket running sums per thread, offset by a
+//                          small scalar multiplication, then a wavefront __shfl_xor butterfly of
+//                          whole points; msm_fold_kernel repeats the butterfly until one point per
+//                          window is left.
+// The W window sums go to the host, which applies the 2^(c*j) weights (Horner) and normalises
+// to the canonical affine point.  Group addition is commutative and the result is canonical, so
+// the non-deterministic order inside a bucket (atomics in step 3) cannot change the output.
+#pragma once
+#include "g1.hpp"
+
+namespace ty {
+
+constexpr uint32_t MSM_SKIP = 0xffffffffu;
+constexpr int MSM_THREADS = 256;
+constexpr int MSM_ACC_THREADS = 64;
+
+__device__ __forceinline__ Fq ld_fq(const uint32_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2];
+    Fq r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w;
+    return r;
+}
+__device__ __forceinline__ void st_fq(uint32_t* p, const Fq& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    q[2] = make_uint4(r.v[8], r.v[9], r.v[10], r.v[11]);
+}
+__device__ __forceinline__ G1Affine ld_affine(const uint32_t* pts, uint64_t idx) {
+    const uint32_t* p = pts + idx * 24;
+    G1Affine r;
+    r.x = ld_fq(p);
+    r.y = ld_fq(p + 12);
+    return r;
+}
+__device__ __forceinline__ G1Xyzz ld_xyzz(const uint32_t* b, uint64_t idx) {
+    const uint32_t* p = b + idx * 48;
+    G1Xyzz r;
+    r.x = ld_fq(p);
+    r.y = ld_fq(p + 12);
+    r.zz = ld_fq(p + 24);
+    r.zzz = ld_fq(p + 36);
+    return r;
+}
+__device__ __forceinline__ void st_xyzz(uint32_t* b, uint64_t idx, const G1Xyzz& r) {
+    uint32_t* p = b + idx * 48;
+    st_fq(p, r.x);
+    st_fq(p + 12, r.y);
+    st_fq(p + 24, r.zz);
+    st_fq(p + 36, r.zzz);
+}
+
+
+}  // namespace ty

@@ -1,0 +1,29 @@
+// Argument block of one NTT pass (see ntt_kernels.hip for the algorithm).
+#pragma once
+#include "ff.hpp"
+
+namespace ty {
+
+struct NttPassArgs {
+    const Fr* in;
+    Fr* out;
+    uint32_t k;        // log2 of this pass's sub-transform size M
+    uint32_t logT;     // log2 of the tile width T
+    uint32_t last;     // 1 for the final (contiguous, digit-reversing) pass
+    uint32_t tw_h;     // split of the inter-pass twiddle exponent
+    uint64_t S;        // stride between consecutive i_p (elements); 1 on the last pass
+    uint64_t row_len;  // M * S
+    // last pass addressing: row rho = k_1 * Q + q ; out = k_1 + N1 * qrev(q) + out_stride * k_P
+    uint64_t N1, Q, N2, N3, out_stride;
+    const Fr* sub_tw;  // w_M^e, e < M/2
+    const Fr* tw_lo;   // w_{row_len}^e,          e < 2^tw_h
+    const Fr* tw_hi;   // w_{row_len}^(e * 2^tw_h)
+    const Fr* pre_lo;  // coset powers g^i applied to the input of pass 1 (forward coset NTT)
+    const Fr* pre_hi;
+    const Fr* post_lo; // g^-k * n^-1 applied to the output of the last pass (inverse coset NTT)
+    const Fr* post_hi;
+    const Fr* scale;   // n^-1 applied to the output of the last pass (plain inverse NTT)
+    uint32_t pre_h, post_h;
+};
+
+}  // namespace ty

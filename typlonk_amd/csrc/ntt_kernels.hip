@@ -14,32 +14,9 @@
 // 1024 elements (32 KiB) and the sub-transform's twiddles w_{N_p}^e are staged in LDS.
 // Inter-pass twiddles and coset powers come from two-level tables (lo[e & mask] * hi[e >> h]),
 // each <= 2^ceil(log/2) entries, so they stay in L2.
-#pragma once
-#include "ff.hpp"
+#include "launch.hpp"
 
 namespace ty {
-
-struct NttPassArgs {
-    const Fr* in;
-    Fr* out;
-    uint32_t k;        // log2 of this pass's sub-transform size M
-    uint32_t logT;     // log2 of the tile width T
-    uint32_t last;     // 1 for the final (contiguous, digit-reversing) pass
-    uint32_t tw_h;     // split of the inter-pass twiddle exponent
-    uint64_t S;        // stride between consecutive i_p (elements); 1 on the last pass
-    uint64_t row_len;  // M * S
-    // last pass addressing: row rho = k_1 * Q + q ; out = k_1 + N1 * qrev(q) + out_stride * k_P
-    uint64_t N1, Q, N2, N3, out_stride;
-    const Fr* sub_tw;  // w_M^e, e < M/2
-    const Fr* tw_lo;   // w_{row_len}^e,          e < 2^tw_h
-    const Fr* tw_hi;   // w_{row_len}^(e * 2^tw_h)
-    const Fr* pre_lo;  // coset powers g^i applied to the input of pass 1 (forward coset NTT)
-    const Fr* pre_hi;
-    const Fr* post_lo; // g^-k * n^-1 applied to the output of the last pass (inverse coset NTT)
-    const Fr* post_hi;
-    const Fr* scale;   // n^-1 applied to the output of the last pass (plain inverse NTT)
-    uint32_t pre_h, post_h;
-};
 
 __device__ __forceinline__ Fr ntt_ld(const Fr* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -138,6 +115,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
             ntt_st(a.out + o, x);
         }
     }
+}
+
+void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(NTT_THREADS), lds_bytes, s, a);
 }
 
 }  // namespace ty

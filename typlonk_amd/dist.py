@@ -1,0 +1,81 @@
+"""Multi-GPU MSM: one process per GPU, index-sharded bases and scalars, one tiny exchange.
+
+    sum_{i<m} k_i P_i  =  sum_g ( sum_{i in shard g} k_i P_i )
+
+Each rank keeps its shard of the SRS resident in HBM (fixed chunking of the base vector, so the
+shard boundaries do not depend on the MSM length m), runs the Pippenger MSM locally and produces
+one canonical affine partial point.  RCCL has no elliptic-curve reduction, so the "all-reduce" of
+the north-star is an all-gather of the G 13-word records (12 limbs + infinity flag) followed by a
+fold in fixed rank order 0..G-1 on every rank (typlonk_g1_sum_host) -- bit-identical everywhere.
+Message size is 104 B per rank: pure latency, xGMI bandwidth is irrelevant.
+
+The local MSM is injected as a callable so that the CPU (gloo, world_size 2) tests can exercise
+the sharding + exchange + fold without a GPU; the product wiring is `ShardedMsm`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .capi import Context, g1_sum_host
+
+
+def shard_bounds(total_len: int, world: int, rank: int) -> tuple[int, int]:
+    """[lo, hi) of the base vector owned by `rank`: equal chunks of ceil(total_len / world)."""
+    chunk = (total_len + world - 1) // world
+    lo = min(rank * chunk, total_len)
+    hi = min(lo + chunk, total_len)
+    return lo, hi
+
+
+def local_range(m: int, total_len: int, world: int, rank: int) -> tuple[int, int]:
+    """portion [lo, hi) of an m-term MSM (m <= total_len) that falls into `rank`'s shard"""
+    lo, hi = shard_bounds(total_len, world, rank)
+    return min(lo, m), min(hi, m)
+
+
+def allgather_fold(partial_xy: np.ndarray, partial_inf: int, device: torch.device, group=None):
+    """all-gather one affine point per rank and fold them in rank order; returns (xy[12], inf)"""
+    world = dist.get_world_size(group)
+    rec = np.zeros(13, dtype=np.uint64)
+    rec[:12] = np.asarray(partial_xy, dtype=np.uint64).reshape(12)
+    rec[12] = partial_inf
+    mine = torch.from_numpy(rec.view(np.int64).copy()).to(device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    allrec = torch.stack(out).cpu().numpy().view(np.uint64)
+    return g1_sum_host(allrec[:, :12].copy(), allrec[:, 12].astype(np.uint8))
+
+
+class ShardedMsm:
+    """SRS shard resident on this rank's GPU + the collective combine."""
+
+    def __init__(self, ctx: Context, total_len: int, rank: int, world: int, device: torch.device, group=None):
+        self.ctx, self.total_len, self.rank, self.world = ctx, total_len, rank, world
+        self.device, self.group = device, group
+        self.lo, self.hi = shard_bounds(total_len, world, rank)
+        self.sid = None
+
+    def generate_srs(self, secret_limbs):
+        """build only this rank's slice [s^lo G, ..., s^(hi-1) G] in HBM"""
+        self.sid = self.ctx.srs_generate(secret_limbs, self.hi - self.lo, start=self.lo)
+        return self.sid
+
+    def load_srs(self, xy_full, inf_full=None):
+        xy = np.asarray(xy_full, dtype=np.uint64).reshape(-1, 12)[self.lo:self.hi]
+        inf = None if inf_full is None else np.asarray(inf_full, dtype=np.uint8)[self.lo:self.hi]
+        self.sid = self.ctx.srs_load(xy, inf)
+        return self.sid
+
+    def msm_local_devptr(self, d_scalars_local: int, m_local: int):
+        """partial sum over this rank's slice; scalars for [lo, lo+m_local) already in HBM"""
+        return self.ctx.msm_devptr(self.sid, d_scalars_local, m_local)
+
+    def msm_devptr(self, d_scalars_local: int, m: int):
+        """full m-term MSM result on every rank"""
+        lo, hi = local_range(m, self.total_len, self.world, self.rank)
+        xy, inf = self.msm_local_devptr(d_scalars_local, hi - lo)
+        if self.world == 1:
+            return xy, inf
+        return allgather_fold(xy, inf, self.device, self.group)
