@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../typlonk_amd/csrc/g1.hpp"
+#include "mul_variants.hpp"
 using namespace ty;
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
@@ -46,6 +47,24 @@ __global__ __launch_bounds__(256) void fmul_kernel(uint32_t* out, int iters) {
     for (int i = 0; i < iters; ++i) { a = fe_mul(a, b); b = fe_mul(b, a); }
     uint32_t s = 0;
     for (int i = 0; i < F::N; ++i) s += a.v[i] ^ b.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void fq_variant_kernel(uint32_t* out, int iters) {
+    uint32_t s = 0;
+    if (V == 2) {
+        Fq a, b;
+        for (int i = 0; i < 12; ++i) { a.v[i] = threadIdx.x * 77u + i * 13u + 1; b.v[i] = blockIdx.x * 31u + i * 7u + 3; }
+        a.v[11] &= 0x0fffffffu; b.v[11] &= 0x0fffffffu;
+        for (int i = 0; i < iters; ++i) { a = fe_mul_ps(a, b); b = fe_mul_ps(b, a); }
+        for (int i = 0; i < 12; ++i) s += a.v[i] ^ b.v[i];
+    } else {
+        Fq30 a, b;
+        for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & MASK30; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & MASK30; }
+        for (int i = 0; i < iters; ++i) { a = fq30_mul(a, b); b = fq30_mul(b, a); }
+        for (int i = 0; i < 13; ++i) s += a.v[i] ^ b.v[i];
+    }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -113,6 +132,15 @@ int main() {
         const int it = 256;
         double t = time_ms([&] { hipLaunchKernelGGL(fmul_kernel<Fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
         printf("Fq mul (12x32 CIOS)      %8.3f ms  %8.2f G mul/s\n", t, (double)blocks * threads * it * 2 / t * 1e-6);
+        for (int occ = 8; occ >= 2; occ /= 2) {
+            const int nb = prop.multiProcessorCount * occ;
+            double t1 = time_ms([&] { hipLaunchKernelGGL(fmul_kernel<Fq>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            double t2 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<2>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            double t3 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<3>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            printf("Fq mul @%d blocks/CU: CIOS %.2f | product-scan asm %.2f | 13x30 unsaturated %.2f  G mul/s\n", occ,
+                   (double)nb * threads * it * 2 / t1 * 1e-6, (double)nb * threads * it * 2 / t2 * 1e-6,
+                   (double)nb * threads * it * 2 / t3 * 1e-6);
+        }
         t = time_ms([&] { hipLaunchKernelGGL(fmul_kernel<Fr>, dim3(blocks), dim3(threads), 0, 0, out, it); });
         printf("Fr mul (8x32 CIOS)       %8.3f ms  %8.2f G mul/s\n", t, (double)blocks * threads * it * 2 / t * 1e-6);
     }

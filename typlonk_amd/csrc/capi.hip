@@ -346,8 +346,8 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
 
 // ---- MSM ------------------------------------------------------------------------------------
 void msm_shape(typlonk_ctx* ctx, size_t m, uint32_t* c_out, uint32_t* w_out) {
-    uint32_t lg = 0;
-    while (((size_t)1 << (lg + 1)) <= m) ++lg;
+    uint32_t lg = 0;  // ceil(log2 m)
+    while (((size_t)1 << lg) < m) ++lg;
     int c = (int)lg - 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
@@ -387,6 +387,9 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     uint32_t c, W;
     msm_shape(ctx, m, &c, &W);
     const uint32_t B = 1u << (c - 1);
+    // top window: t scalar bits -> 2^t digits, spread over 2^top_v virtual bucket copies
+    const uint32_t t_bits = 255 - c * (W - 1);
+    const uint32_t top_v = (t_bits >= c - 1) ? 0u : (c - 1 - t_bits);
     const uint64_t nb = (uint64_t)W * B;
     const uint64_t total = (uint64_t)W * m;
     if (total >= (1ull << 31)) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM too large for 32-bit entry indices");
@@ -420,7 +423,7 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     {
         StageTimer st(ctx, "msm_digits");
         HIPCHK(hipMemsetAsync(counts, 0, nb * 4, s));
-        launch_msm_digits(d_scalars, (uint64_t)m, c, W, keys, counts, s);
+        launch_msm_digits(d_scalars, (uint64_t)m, c, W, top_v, keys, counts, s);
     }
     {
         StageTimer st(ctx, "msm_scan");
@@ -440,7 +443,7 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     {
         StageTimer st(ctx, "msm_reduce");
         const uint32_t group = std::min<uint32_t>(64, npw);
-        launch_msm_reduce(buckets, B, L, nodes, group, c, cur, s);
+        launch_msm_reduce(buckets, B, L, nodes, group, c, W, top_v, cur, s);
         n_in = npw / group;
         while (n_in > 1) {
             const uint32_t g2 = std::min<uint32_t>(64, n_in);

@@ -14,8 +14,8 @@ constexpr int MSM_SEG = 8;            // buckets per reduce thread
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s);
 
 void launch_mark_inf(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);
-void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t* keys, uint32_t* counts,
-                       hipStream_t s);
+void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t* keys,
+                       uint32_t* counts, hipStream_t s);
 void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor,
                  hipStream_t s);
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
@@ -23,7 +23,7 @@ void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, uint32_t nbuckets,
                       uint32_t* buckets, hipStream_t s);
 void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
-                       uint32_t cbits, uint32_t* partials, hipStream_t s);
+                       uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s);
 void launch_msm_fold(const uint32_t* in, uint32_t total, uint32_t group, uint32_t* out, hipStream_t s);
 void launch_srs_generate(const Fr& s, uint64_t start, uint64_t n, uint32_t* pts, hipStream_t st);
 

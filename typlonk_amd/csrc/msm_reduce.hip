@@ -17,26 +17,30 @@ __device__ __forceinline__ G1Xyzz shfl_xor_point(const G1Xyzz& p, int mask) {
 }
 
 // Thread t owns buckets [t*L, (t+1)*L) of the flat (window-major) bucket array, L = min(8, B).
-// node value = sum_l (s*L + l + 1) * bucket[l]   with s = t mod (B/L);
+// node value = sum_l w(s*L + l) * bucket[l]   with s = t mod (B/L) and bucket weight
+// w(k) = (k >> v) + 1, v = 0 except in the top window (v = top_v, see msm_digits_kernel);
 // lanes of the same window are then summed with a __shfl_xor butterfly over `group` lanes and
 // lane 0 of each group stores one partial.  partials[t / group].
 __global__ __launch_bounds__(64) void msm_reduce_kernel(const uint32_t* __restrict__ buckets, uint32_t B, uint32_t L,
                                                         uint32_t nodes_total, uint32_t group, uint32_t cbits,
-                                                        uint32_t* partials) {
+                                                        uint32_t W, uint32_t top_v, uint32_t* partials) {
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
     G1Xyzz v = G1Xyzz::inf();
     if (t < nodes_total) {
         const uint32_t npw = B / L;
         const uint32_t s = t % npw;
+        const uint32_t wv = (t / npw + 1 == W) ? top_v : 0u;
+        const uint32_t vmask = (1u << wv) - 1;
         const uint64_t base = (uint64_t)t * L;
+        // u = sum_l (w(k0 + l) - w(k0)) * x_l : the running sum is added once per weight step
         G1Xyzz running = G1Xyzz::inf(), u = G1Xyzz::inf();
         for (uint32_t l = L - 1; l >= 1; --l) {
             running = g1_add(running, ld_xyzz(buckets, base + l));
-            u = g1_add(u, running);
+            if (((s * L + l) & vmask) == 0) u = g1_add(u, running);
         }
         running = g1_add(running, ld_xyzz(buckets, base));
-        // (s*L + 1) * S by double-and-add over cbits bits
-        const uint32_t kmul = s * L + 1;
+        // w(k0) * S by double-and-add over cbits bits
+        const uint32_t kmul = ((s * L) >> wv) + 1;
         G1Xyzz acc = G1Xyzz::inf();
         for (int bit = (int)cbits - 1; bit >= 0; --bit) {
             acc = g1_dbl(acc);
@@ -66,9 +70,9 @@ __global__ __launch_bounds__(64) void msm_fold_kernel(const uint32_t* __restrict
 
 
 void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
-                       uint32_t cbits, uint32_t* partials, hipStream_t s) {
+                       uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s) {
     hipLaunchKernelGGL(msm_reduce_kernel, dim3((nodes_total + 63) / 64), dim3(64), 0, s, buckets, B, L, nodes_total, group,
-                       cbits, partials);
+                       cbits, W, top_v, partials);
 }
 void launch_msm_fold(const uint32_t* in, uint32_t total, uint32_t group, uint32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(msm_fold_kernel, dim3((total + 63) / 64), dim3(64), 0, s, in, total, group, out);

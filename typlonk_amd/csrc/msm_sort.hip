@@ -26,8 +26,16 @@ __device__ __forceinline__ uint32_t msm_bits(const uint32_t (&v)[8], uint32_t o,
 }
 
 // keys[j*m + i] = bucket id (j*B + |d| - 1) | sign << 31, or MSM_SKIP for a zero digit
+//
+// The top window holds only t = 255 - c*(W-1) scalar bits (plus the carry), i.e. 2^t distinct
+// digits: taken as is, its buckets would each receive m/2^t entries -- up to m/2 in one bucket --
+// while every other window's buckets receive m/2^(c-1).  Its entries are therefore spread over
+// V = 2^top_v "virtual copies" of each digit's bucket (copy = i mod V), so that the top window fills
+// the same 2^(c-1) buckets as evenly as the others; the reduction weighs bucket k of that window
+// by (k >> top_v) + 1.
 __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* scalars, uint64_t m, uint32_t c,
-                                                                 uint32_t W, uint32_t* keys, uint32_t* counts) {
+                                                                 uint32_t W, uint32_t top_v, uint32_t* keys,
+                                                                 uint32_t* counts) {
     const uint64_t i = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
     if (i >= m) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + i);
@@ -50,7 +58,8 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const Fr* scala
         }
         uint32_t key = MSM_SKIP;
         if (d != 0) {
-            const uint32_t bucket = j * B + d - 1;
+            const uint32_t bucket = (j + 1 == W) ? j * B + ((d - 1) << top_v) + ((uint32_t)i & ((1u << top_v) - 1))
+                                                 : j * B + d - 1;
             key = bucket | (neg << 31);
             atomicAdd(&counts[bucket], 1u);
         }
@@ -144,10 +153,10 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const uint32_t
 void launch_mark_inf(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(msm_mark_inf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pts, inf, n);
 }
-void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t* keys, uint32_t* counts,
-                       hipStream_t s) {
+void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t* keys,
+                       uint32_t* counts, hipStream_t s) {
     hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((m + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, s,
-                       scalars, m, c, W, keys, counts);
+                       scalars, m, c, W, top_v, keys, counts);
 }
 void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor,
                  hipStream_t s) {
