@@ -1,12 +1,23 @@
 // Host-side test shim: exposes the product's shared host/device arithmetic headers
-// (typlonk_amd/csrc/ff.hpp, g1.hpp) through a C ABI so pytest can check them against the
+// (typlonk_amd/csrc/ff.hpp, fq30.hpp, g1.hpp) through a C ABI so pytest can check them against the
 // Python big-int oracle without a GPU.  Built by __graft_entry__.build() with g++.
+// All Fq / G1 arguments are in the C-ABI (arkworks) form: 12 u32 words per coordinate, R = 2^384.
 #include "../../typlonk_amd/csrc/g1.hpp"
 #include <string.h>
 using namespace ty;
 
 template <class F> static F ld(const uint32_t* p) { F f; memcpy(f.v, p, sizeof(f.v)); return f; }
 template <class F> static void st(uint32_t* p, const F& f) { memcpy(p, f.v, sizeof(f.v)); }
+
+static Fq30 ldq(const uint32_t* p) { uint32_t w[12]; memcpy(w, p, 48); return fq30_from_ark(w); }
+static void stq(uint32_t* p, const Fq30& a) { uint32_t w[12]; fq30_to_ark(a, w); memcpy(p, w, 48); }
+
+// scale a value up by adding k*p without changing it mod p (exercises the lazy-bound paths)
+static Fq30 lift(const Fq30& a, int k) {
+    Fq30 r = a;
+    for (int j = 0; j < k; ++j) { Fq30 pp; for (int i = 0; i < 13; ++i) pp.v[i] = fq30_kp(1, i); r = fq30_add_lazy(r, pp); }
+    return r;
+}
 
 extern "C" {
 void shim_fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_mul(ld<Fr>(a), ld<Fr>(b))); }
@@ -15,38 +26,63 @@ void shim_fr_sub(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_s
 void shim_fr_inv(const uint32_t* a, uint32_t* o) { st(o, fe_inv(ld<Fr>(a))); }
 void shim_fr_from_mont(const uint32_t* a, uint32_t* o) { st(o, fe_from_mont(ld<Fr>(a))); }
 void shim_fr_to_mont(const uint32_t* a, uint32_t* o) { st(o, fe_to_mont(ld<Fr>(a))); }
-void shim_fq_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_mul(ld<Fq>(a), ld<Fq>(b))); }
-void shim_fq_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_add(ld<Fq>(a), ld<Fq>(b))); }
-void shim_fq_sub(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_sub(ld<Fq>(a), ld<Fq>(b))); }
-void shim_fq_neg(const uint32_t* a, uint32_t* o) { st(o, fe_neg(ld<Fq>(a))); }
-void shim_fq_dbl(const uint32_t* a, uint32_t* o) { st(o, fe_dbl(ld<Fq>(a))); }
-void shim_fq_inv(const uint32_t* a, uint32_t* o) { st(o, fe_inv(ld<Fq>(a))); }
-void shim_fq_from_mont(const uint32_t* a, uint32_t* o) { st(o, fe_from_mont(ld<Fq>(a))); }
 
-// points: 24 u32 (x||y Montgomery); identity = all zero.  acc/out: affine, same encoding.
-static G1Affine lda(const uint32_t* p) { G1Affine a; a.x = ld<Fq>(p); a.y = ld<Fq>(p + 12); return a; }
-static void sta(uint32_t* p, const G1Affine& a) { st(p, a.x); st(p + 12, a.y); }
+// Fq30: la / lb = number of extra multiples of p added to the operands before the operation
+void shim_fq_roundtrip(const uint32_t* a, uint32_t* o) { stq(o, ldq(a)); }
+void shim_fq_mul(const uint32_t* a, const uint32_t* b, int la, int lb, uint32_t* o) { stq(o, fq30_mul(lift(ldq(a), la), lift(ldq(b), lb))); }
+void shim_fq_sqr(const uint32_t* a, int la, uint32_t* o) { stq(o, fq30_sqr(lift(ldq(a), la))); }
+void shim_fq_add(const uint32_t* a, const uint32_t* b, int la, int lb, uint32_t* o) { stq(o, fq30_add_lazy(lift(ldq(a), la), lift(ldq(b), lb))); }
+void shim_fq_sub(const uint32_t* a, const uint32_t* b, int la, int lb, uint32_t* o) {  // b + lb*p <= 6p
+    stq(o, fq30_sub_lazy<6>(lift(ldq(a), la), lift(ldq(b), lb)));
+}
+void shim_fq_sub2(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* o) {
+    stq(o, fq30_sub2_lazy<4>(lift(ldq(a), 1), lift(ldq(b), 1), lift(ldq(c), 1)));
+}
+void shim_fq_mul3(const uint32_t* a, uint32_t* o) { stq(o, fq30_mulk_lazy<3>(lift(ldq(a), 1))); }
+void shim_fq_neg(const uint32_t* a, uint32_t* o) { stq(o, fq30_neg_lazy<1>(ldq(a))); }
+void shim_fq_inv(const uint32_t* a, uint32_t* o) { stq(o, fq30_inv(ldq(a))); }
+int shim_fq_is_zero_mod(const uint32_t* a, int la) { return fq30_is_zero_mod(lift(ldq(a), la)) ? 1 : 0; }
+// pack(unpack(w)) on raw words (any 384-bit pattern whose value is < 2^384)
+void shim_fq_pack_unpack(const uint32_t* w, uint32_t* o) { uint32_t t[12]; memcpy(t, w, 48); uint32_t r[12]; fq30_pack(fq30_unpack(t), r); memcpy(o, r, 48); }
 
-// out = a + (neg ? -b : b) through the mixed-add path (a lifted to XYZZ with a random-looking Z
-// when `scramble` != 0 so the projective formulas are really exercised)
+// points: 24 u32 (x||y, arkworks form); identity = all zero.
+static G1Affine lda(const uint32_t* p) {
+    bool z = true; for (int i = 0; i < 24; ++i) z = z && p[i] == 0;
+    if (z) return G1Affine::inf();
+    G1Affine a; a.x = ldq(p); a.y = ldq(p + 12); return a;
+}
+static void sta(uint32_t* p, const G1Affine& a) {
+    if (a.is_inf()) { memset(p, 0, 96); return; }
+    stq(p, a.x); stq(p + 12, a.y);
+}
+static void scramble(G1Xyzz& p, const uint32_t* z) {
+    if (!z || p.is_inf()) return;
+    Fq30 zv = ldq(z), zz = fq30_sqr(zv), zzz = fq30_mul(zz, zv);
+    p.x = fq30_mul(p.x, zz); p.y = fq30_mul(p.y, zzz); p.zz = zz; p.zzz = zzz;
+}
+
+// out = a + (neg ? -b : b) through the mixed-add path (a lifted to XYZZ with a random Z when given)
 void shim_g1_madd(const uint32_t* a, const uint32_t* b, int neg, const uint32_t* z, uint32_t* o) {
     G1Xyzz acc = G1Xyzz::from_affine(lda(a));
-    if (z && !acc.is_inf()) {
-        Fq zz = fe_sqr(ld<Fq>(z)), zzz = fe_mul(zz, ld<Fq>(z));
-        acc.x = fe_mul(acc.x, zz); acc.y = fe_mul(acc.y, zzz); acc.zz = zz; acc.zzz = zzz;
-    }
+    scramble(acc, z);
     g1_madd(acc, lda(b), neg != 0);
     sta(o, g1_to_affine(acc));
 }
 void shim_g1_add(const uint32_t* a, const uint32_t* b, const uint32_t* z1, const uint32_t* z2, uint32_t* o) {
     G1Xyzz pa = G1Xyzz::from_affine(lda(a)), pb = G1Xyzz::from_affine(lda(b));
-    if (z1 && !pa.is_inf()) { Fq zz = fe_sqr(ld<Fq>(z1)), zzz = fe_mul(zz, ld<Fq>(z1));
-        pa.x = fe_mul(pa.x, zz); pa.y = fe_mul(pa.y, zzz); pa.zz = zz; pa.zzz = zzz; }
-    if (z2 && !pb.is_inf()) { Fq zz = fe_sqr(ld<Fq>(z2)), zzz = fe_mul(zz, ld<Fq>(z2));
-        pb.x = fe_mul(pb.x, zz); pb.y = fe_mul(pb.y, zzz); pb.zz = zz; pb.zzz = zzz; }
+    scramble(pa, z1); scramble(pb, z2);
     sta(o, g1_to_affine(g1_add(pa, pb)));
 }
 void shim_g1_mul_small(const uint32_t* a, uint32_t k, uint32_t* o) {
     sta(o, g1_to_affine(g1_mul_small(G1Xyzz::from_affine(lda(a)), k)));
+}
+// long chain: acc = sum_i (+/-) pts[i] via repeated mixed adds, then n doublings -- checks that the
+// lazy bounds hold over many dependent operations
+void shim_g1_chain(const uint32_t* pts, int n, int ndbl, uint32_t* o) {
+    G1Xyzz acc = G1Xyzz::inf();
+    for (int i = 0; i < n; ++i) g1_madd(acc, lda(pts + 24 * i), (i % 3) == 1);
+    for (int i = 0; i < ndbl; ++i) acc = g1_dbl(acc);
+    G1Xyzz acc2 = g1_add(acc, acc);
+    sta(o, g1_to_affine(acc2));
 }
 }

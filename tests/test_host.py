@@ -31,10 +31,9 @@ def _call(shim, fn, n, *args):
     return [int(v) for v in o]
 
 
-def test_field_arithmetic_vs_bigint(shim):
+def test_fr_arithmetic_vs_bigint(shim):
     rnd = random.Random(1)
     er = [0, 1, 2, O.R - 1, O.R - 2, (1 << 255) % O.R, (1 << 32) - 1, 1 << 32]
-    ep = [0, 1, 2, O.P - 1, O.P - 2, (1 << 381) % O.P, (1 << 32) - 1]
     for it in range(600):
         a = rnd.choice(er) if it < 64 else rnd.randrange(O.R)
         b = er[it % 8] if it < 64 else rnd.randrange(O.R)
@@ -43,17 +42,46 @@ def test_field_arithmetic_vs_bigint(shim):
         assert O.fr_from_mont_limbs(_call(shim, "shim_fr_sub", 4, _fr(a), _fr(b))) == (a - b) % O.R
         x = _call(shim, "shim_fr_from_mont", 4, _fr(a))
         assert sum(v << (64 * i) for i, v in enumerate(x)) == a
-        a = rnd.choice(ep) if it < 64 else rnd.randrange(O.P)
-        b = ep[it % 7] if it < 64 else rnd.randrange(O.P)
-        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_mul", 6, _fq(a), _fq(b))) == a * b % O.P
-        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_add", 6, _fq(a), _fq(b))) == (a + b) % O.P
-        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_sub", 6, _fq(a), _fq(b))) == (a - b) % O.P
-        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_neg", 6, _fq(a))) == (-a) % O.P
-        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_dbl", 6, _fq(a))) == (2 * a) % O.P
-    for a in [1, 2, 5, rnd.randrange(O.P)]:
-        assert O.fq_from_mont_limbs(_call(shim, "shim_fq_inv", 6, _fq(a))) == pow(a, -1, O.P)
     for a in [1, 2, 5, rnd.randrange(O.R)]:
         assert O.fr_from_mont_limbs(_call(shim, "shim_fr_inv", 4, _fr(a))) == pow(a, -1, O.R)
+
+
+def _q(shim, fn, *args):
+    """call a shim Fq function: numpy arrays are passed as u32 pointers, ints as ints"""
+    o = np.zeros(6, dtype=np.uint64)
+    getattr(shim, fn)(*[u32p(a) if isinstance(a, np.ndarray) else a for a in args], u32p(o))
+    return O.fq_from_mont_limbs([int(v) for v in o])
+
+
+def test_fq30_arithmetic_vs_bigint(shim):
+    """13 x 30-bit lazily reduced Fq: every operation, with operands lifted by multiples of p up to
+    the bounds the group law uses, against Python big ints (through the arkworks in/out conversions)"""
+    rnd = random.Random(3)
+    ep = [0, 1, 2, O.P - 1, O.P - 2, (1 << 380) % O.P, (1 << 30) - 1, 1 << 30, (1 << 360) - 1]
+    for it in range(400):
+        a = ep[it % 9] if it < 81 else rnd.randrange(O.P)
+        b = ep[(it // 9) % 9] if it < 81 else rnd.randrange(O.P)
+        c = rnd.randrange(O.P)
+        la, lb = rnd.randrange(0, 7), rnd.randrange(0, 7)
+        assert _q(shim, "shim_fq_roundtrip", _fq(a)) == a
+        assert _q(shim, "shim_fq_mul", _fq(a), _fq(b), la, lb) == a * b % O.P
+        assert _q(shim, "shim_fq_sqr", _fq(a), la) == a * a % O.P
+        assert _q(shim, "shim_fq_add", _fq(a), _fq(b), la % 4, lb % 4) == (a + b) % O.P
+        assert _q(shim, "shim_fq_sub", _fq(a), _fq(b), la, lb % 6) == (a - b) % O.P
+        assert _q(shim, "shim_fq_sub2", _fq(a), _fq(b), _fq(c)) == (a - b - c) % O.P
+        assert _q(shim, "shim_fq_mul3", _fq(a)) == 3 * a % O.P
+        assert _q(shim, "shim_fq_neg", _fq(a)) == (-a) % O.P
+        assert shim.shim_fq_is_zero_mod(u32p(_fq(a)), 0) == (1 if a == 0 else 0)
+    assert shim.shim_fq_is_zero_mod(u32p(_fq(0)), 1) == 1       # the value p itself
+    assert shim.shim_fq_is_zero_mod(u32p(_fq(1)), 1) == 0
+    for a in [1, 2, 5, O.P - 1, rnd.randrange(O.P)]:
+        assert _q(shim, "shim_fq_inv", _fq(a)) == pow(a, -1, O.P)
+    # pack/unpack is the identity on any 384-bit word pattern
+    for _ in range(50):
+        w = np.array([rnd.getrandbits(64) for _ in range(6)], dtype=np.uint64)
+        o = np.zeros(6, dtype=np.uint64)
+        shim.shim_fq_pack_unpack(u32p(w), u32p(o))
+        assert (o == w).all()
 
 
 def _pt(p):
@@ -89,6 +117,18 @@ def test_group_law_all_exceptional_cases(shim):
         o = np.zeros(12, dtype=np.uint64)
         shim.shim_g1_mul_small(u32p(_pt(pts[3])), k, u32p(o))
         assert _unpt(o) == O.g1_mul(pts[3], k)
+
+
+def test_group_law_long_dependent_chain(shim):
+    """200 dependent mixed adds (every third negated) + 40 doublings + one full add: the lazy
+    reduction bounds must hold along the whole chain"""
+    n, ndbl = 200, 40
+    pts = O.srs_from_secret_fast(3, n)
+    arr = np.concatenate([_pt(p) for p in pts])
+    o = np.zeros(12, dtype=np.uint64)
+    shim.shim_g1_chain(u32p(arr), n, ndbl, u32p(o))
+    k = sum((-1 if i % 3 == 1 else 1) * pow(3, i, O.R) for i in range(n)) % O.R
+    assert _unpt(o) == O.g1_mul(O.G1, k * pow(2, ndbl + 1, O.R) % O.R)
 
 
 def test_library_loads_and_exports_every_declared_symbol(built):

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void fq_variant_kernel(uint32_t* out, int iter
         for (int i = 0; i < 12; ++i) s += a.v[i] ^ b.v[i];
     } else {
         Fq30 a, b;
-        for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & MASK30; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & MASK30; }
+        for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & FQ30_MASK; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & FQ30_MASK; }
         for (int i = 0; i < iters; ++i) { a = fq30_mul(a, b); b = fq30_mul(b, a); }
         for (int i = 0; i < 13; ++i) s += a.v[i] ^ b.v[i];
     }

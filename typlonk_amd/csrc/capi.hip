@@ -356,18 +356,37 @@ void msm_shape(typlonk_ctx* ctx, size_t m, uint32_t* c_out, uint32_t* w_out) {
     *w_out = (256 + c - 1) / c;
 }
 
+// internal affine -> the C-ABI's arkworks form
 void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf) {
+    uint32_t w[12];
     if (a.is_inf()) {
-        // ark-ec GroupAffine::zero(): x = 0, y = 1 (Montgomery one), infinity = true
-        Fq one = Fq::one();
+        // ark-ec GroupAffine::zero(): x = 0, y = 1 (Montgomery one, R = 2^384), infinity = true
         memset(out_xy, 0, 6 * sizeof(uint64_t));
-        memcpy(out_xy + 6, one.v, sizeof(one.v));
+        fq30_to_ark(fq30_one(), w);
+        memcpy(out_xy + 6, w, sizeof(w));
         *out_inf = 1;
     } else {
-        memcpy(out_xy, a.x.v, sizeof(a.x.v));
-        memcpy(out_xy + 6, a.y.v, sizeof(a.y.v));
+        fq30_to_ark(a.x, w);
+        memcpy(out_xy, w, sizeof(w));
+        fq30_to_ark(a.y, w);
+        memcpy(out_xy + 6, w, sizeof(w));
         *out_inf = 0;
     }
+}
+
+// packed device words -> host XYZZ
+G1Xyzz unpack_xyzz(const uint32_t* p) {
+    G1Xyzz r;
+    uint32_t w[12];
+    memcpy(w, p, 48);
+    r.x = fq30_unpack(w);
+    memcpy(w, p + 12, 48);
+    r.y = fq30_unpack(w);
+    memcpy(w, p + 24, 48);
+    r.zz = fq30_unpack(w);
+    memcpy(w, p + 36, 48);
+    r.zzz = fq30_unpack(w);
+    return r;
 }
 
 int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12],
@@ -454,9 +473,11 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
         }
     }
     HIPCHK(hipGetLastError());
-    std::vector<G1Xyzz> wins(W);
-    HIPCHK(hipMemcpyAsync(wins.data(), cur, (size_t)W * 192, hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> wins_raw((size_t)W * 48);
+    HIPCHK(hipMemcpyAsync(wins_raw.data(), cur, (size_t)W * 192, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    std::vector<G1Xyzz> wins(W);
+    for (uint32_t j = 0; j < W; ++j) wins[j] = unpack_xyzz(wins_raw.data() + (size_t)j * 48);
     // host: sum_j 2^(c*j) * wins[j]  (Horner from the top window), then canonical affine
     G1Xyzz acc = G1Xyzz::inf();
     for (int j = (int)W - 1; j >= 0; --j) {
@@ -549,15 +570,15 @@ int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, s
     HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * 96));
     if (len) {
         HIPCHK(hipMemcpyAsync(e.d_points, xy, len * 96, hipMemcpyHostToDevice, ctx->stream));
+        uint8_t* d_inf = nullptr;
         if (inf) {
-            uint8_t* d_inf = nullptr;
             HIPCHK(hipMalloc((void**)&d_inf, len));
             HIPCHK(hipMemcpyAsync(d_inf, inf, len, hipMemcpyHostToDevice, ctx->stream));
-            launch_mark_inf(e.d_points, d_inf, (uint64_t)len, ctx->stream);
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            HIPCHK(hipFree(d_inf));
         }
+        launch_convert_points(e.d_points, d_inf, (uint64_t)len, ctx->stream);  // arkworks -> internal form
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (d_inf) HIPCHK(hipFree(d_inf));
     }
     const uint32_t id = ctx->next_srs++;
     ctx->srs[id] = e;
@@ -610,12 +631,16 @@ int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_
     if (!count) return TYPLONK_OK;
     HIPCHK(hipMemcpyAsync(xy, it->second.d_points + offset * 24, count * 96, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    Fq one = Fq::one();
-    for (size_t i = 0; i < count; ++i) {  // device encoding (0,0) -> ark-ec (0, 1, inf)
-        bool z = true;
-        for (int w = 0; w < 12; ++w) z = z && xy[i * 12 + w] == 0;
-        if (inf) inf[i] = z ? 1 : 0;
-        if (z) memcpy(xy + i * 12 + 6, one.v, sizeof(one.v));
+    for (size_t i = 0; i < count; ++i) {  // internal packed form -> arkworks; (0,0) -> ark-ec (0, 1, inf)
+        G1Affine a;
+        uint32_t w[12];
+        memcpy(w, xy + i * 12, 48);
+        a.x = fq30_unpack(w);
+        memcpy(w, xy + i * 12 + 6, 48);
+        a.y = fq30_unpack(w);
+        uint8_t f = 0;
+        write_affine_out(a, xy + i * 12, &f);
+        if (inf) inf[i] = f;
     }
     return TYPLONK_OK;
 }
@@ -739,8 +764,11 @@ int typlonk_g1_sum_host(const uint64_t* xy, const uint8_t* inf, size_t count, ui
     for (size_t i = 0; i < count; ++i) {
         if (inf && inf[i]) continue;
         G1Affine p;
-        memcpy(p.x.v, xy + i * 12, sizeof(p.x.v));
-        memcpy(p.y.v, xy + i * 12 + 6, sizeof(p.y.v));
+        uint32_t w[12];
+        memcpy(w, xy + i * 12, 48);
+        p.x = fq30_from_ark(w);
+        memcpy(w, xy + i * 12 + 6, 48);
+        p.y = fq30_from_ark(w);
         g1_madd(acc, p, false);
     }
     write_affine_out(g1_to_affine(acc), out_xy, out_inf);

@@ -1,0 +1,305 @@
+// BLS12-381 base field Fq on 13 unsaturated 30-bit limbs -- the arithmetic of the MSM hot path
+// (replaces ark-ff 0.3.0 Fp384 as used by ark-ec's group law; reference call sites
+// /root/reference/kzg/src/lib.rs:49-52).
+//
+// Why 30-bit limbs.  Measured on MI355X (profiles/r01_ubench_*.txt): v_mad_u64_u32
+// (32x32+64 -> 64) issues at ~5.3 cycles per wave, an add-with-carry at ~4.4, and a saturated
+// 12x32-bit CIOS multiplication needs two carry adds per mad, so the carries cost more than the
+// multiplies (40 G mul/s).  With 30-bit limbs a column of 13 partial products is < 13 * 2^60 <
+// 2^64: a whole column accumulates in one 64-bit register with NOTHING but mads, and carries are
+// resolved once per column (73 G mul/s, 1.8x).
+//
+// Representation.  x = sum v[i] * 2^(30 i), every limb < 2^30 ("normalised").  Montgomery domain
+// with R = 2^390.  Values are kept LAZILY reduced: R / p = 2^9.3 ~ 630, so a Montgomery product of
+// inputs a < A*p, b < B*p is < (1 + A*B/630) * p -- inputs may be several p large and the output
+// is still ~p.  Every function documents its bound contract in units of p; the group law in
+// g1.hpp states the bound of every intermediate.  Zero tests are exact tests mod p on values
+// known to be < 2p (value in {0, p}).
+//
+// Memory format.  In HBM a field element is packed into 12 x 32-bit words (384 bits; every stored
+// value is < 8p < 2^384), so points stay 96 B and XYZZ buckets 192 B with 16-byte alignment;
+// pack/unpack are a few dozen shifts next to a ~2200-cycle multiplication.
+//
+// The same header compiles for the host (final window combine, affine normalisation, folds).
+#pragma once
+#include <stdint.h>
+
+#include "ff.hpp"
+
+namespace ty {
+
+struct Fq30 {
+    uint32_t v[13];
+};
+
+constexpr uint32_t FQ30_MASK = 0x3fffffffu;
+constexpr uint32_t FQ30_NINV = 0x3ffcfffdu;  // -p^-1 mod 2^30
+
+// k*p for k = 1..8 as normalised 30-bit digits
+TY_HD constexpr uint32_t fq30_kp(int k, int i) {
+    constexpr uint32_t t[8][13] = {
+        /* 1p */ {0x3fffaaabu, 0x27fbffffu, 0x153ffffbu, 0x2affffacu, 0x30f6241eu, 0x034a83dau, 0x112bf673u, 0x12e13ce1u, 0x2cd76477u, 0x1ed90d2eu, 0x29a4b1bau, 0x3a8e5ff9u, 0x001a0111u},
+        /* 2p */ {0x3fff5556u, 0x0ff7ffffu, 0x2a7ffff7u, 0x15ffff58u, 0x21ec483du, 0x069507b5u, 0x2257ece6u, 0x25c279c2u, 0x19aec8eeu, 0x3db21a5du, 0x13496374u, 0x351cbff3u, 0x00340223u},
+        /* 3p */ {0x3fff0001u, 0x37f3ffffu, 0x3fbffff2u, 0x00ffff04u, 0x12e26c5cu, 0x09df8b90u, 0x3383e359u, 0x38a3b6a3u, 0x06862d65u, 0x1c8b278cu, 0x3cee152fu, 0x2fab1fecu, 0x004e0335u},
+        /* 4p */ {0x3ffeaaacu, 0x1fefffffu, 0x14ffffeeu, 0x2bfffeb1u, 0x03d8907au, 0x0d2a0f6bu, 0x04afd9ccu, 0x0b84f385u, 0x335d91ddu, 0x3b6434bau, 0x2692c6e9u, 0x2a397fe6u, 0x00680447u},
+        /* 5p */ {0x3ffe5557u, 0x07ebffffu, 0x2a3fffeau, 0x16fffe5du, 0x34ceb499u, 0x10749345u, 0x15dbd03fu, 0x1e663066u, 0x2034f654u, 0x1a3d41e9u, 0x103778a4u, 0x24c7dfe0u, 0x00820559u},
+        /* 6p */ {0x3ffe0002u, 0x2fe7ffffu, 0x3f7fffe5u, 0x01fffe09u, 0x25c4d8b8u, 0x13bf1720u, 0x2707c6b2u, 0x31476d47u, 0x0d0c5acbu, 0x39164f18u, 0x39dc2a5eu, 0x1f563fd9u, 0x009c066bu},
+        /* 7p */ {0x3ffdaaadu, 0x17e3ffffu, 0x14bfffe1u, 0x2cfffdb6u, 0x16bafcd6u, 0x17099afbu, 0x3833bd25u, 0x0428aa28u, 0x39e3bf43u, 0x17ef5c46u, 0x2380dc19u, 0x19e49fd3u, 0x00b6077du},
+        /* 8p */ {0x3ffd5558u, 0x3fdfffffu, 0x29ffffdcu, 0x17fffd62u, 0x07b120f5u, 0x1a541ed6u, 0x095fb398u, 0x1709e70au, 0x26bb23bau, 0x36c86975u, 0x0d258dd3u, 0x1472ffcdu, 0x00d0088fu}};
+    return t[k - 1][i];
+}
+// R mod p = Montgomery one
+TY_HD constexpr uint32_t fq30_one_limb(int i) {
+    constexpr uint32_t t[13] = {0x00d1ff2eu, 0x19d80000u, 0x34800ac4u, 0x2e00cde6u, 0x02431c84u, 0x269f83a2u, 0x3dcf80ddu,
+                                0x09b42da0u, 0x25eec26cu, 0x15d98f12u, 0x04b29f14u, 0x259fcfa0u, 0x00015de9u};
+    return t[i];
+}
+// 2^396 mod p : montmul(y, C_IN) turns an arkworks residue y = x*2^384 into x*2^390
+TY_HD constexpr uint32_t fq30_cin_limb(int i) {
+    constexpr uint32_t t[13] = {0x3480cb7fu, 0x3e0c0000u, 0x2042b126u, 0x3f337aafu, 0x3de4b4d1u, 0x1e015cf1u, 0x005c540du,
+                                0x3467b19au, 0x352a6da3u, 0x19d89d19u, 0x2fb9afe6u, 0x3848c817u, 0x0009772fu};
+    return t[i];
+}
+// 2^384 mod p : montmul(x*2^390, C_OUT) = x*2^384, the arkworks residue
+TY_HD constexpr uint32_t fq30_cout_limb(int i) {
+    constexpr uint32_t t[13] = {0x0002fffdu, 0x18240000u, 0x00c00027u, 0x3d0002f1u, 0x0758baebu, 0x22615d4fu, 0x257455f4u,
+                                0x1614dc14u, 0x2c6d77ceu, 0x2a5e895bu, 0x0935c071u, 0x30fea039u, 0x0015f65eu};
+    return t[i];
+}
+
+TY_HD Fq30 fq30_zero() {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.v[i] = 0;
+    return r;
+}
+TY_HD Fq30 fq30_one() {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.v[i] = fq30_one_limb(i);
+    return r;
+}
+
+// ---- multiplication -----------------------------------------------------------------------------
+// Montgomery reduction of a 26-digit product T (T[25] may exceed 30 bits): T * 2^-390 mod p,
+// result < p + T / 2^390, normalised.
+TY_HD Fq30 fq30_redc(const uint32_t (&T)[26]) {
+    uint32_t m[13];
+    Fq30 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        acc += T[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
+        m[k] = ((uint32_t)acc * FQ30_NINV) & FQ30_MASK;
+        acc += (uint64_t)m[k] * fq30_kp(1, 0);
+        acc >>= 30;
+    }
+#pragma unroll
+    for (int k = 13; k < 26; ++k) {
+        acc += T[k];
+#pragma unroll
+        for (int i = k - 12; i < 13; ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
+        r.v[k - 13] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    return r;
+}
+
+// a*b*2^-390 mod p.  Needs normalised limbs and a*b < 2^780; output < (1 + A*B/630) p for
+// a < A p, b < B p.  338 + 26 mads, no carry instructions inside a column.
+TY_HD Fq30 fq30_mul(const Fq30& a, const Fq30& b) {
+    uint32_t T[26];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+#pragma unroll
+        for (int i = (k > 12 ? k - 12 : 0); i <= (k < 12 ? k : 12); ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        T[k] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    T[25] = (uint32_t)acc;
+    return fq30_redc(T);
+}
+
+// a*a*2^-390 mod p: cross terms once with a doubled operand (91 mads in the product phase).
+// Column bound: 6 * 2^61 + 2^60 < 2^64.
+TY_HD Fq30 fq30_sqr(const Fq30& a) {
+    uint32_t T[26];
+    uint32_t d[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) d[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        const int lo = (k > 12 ? k - 12 : 0);
+#pragma unroll
+        for (int i = lo; 2 * i < k; ++i) acc += (uint64_t)d[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+        T[k] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    T[25] = (uint32_t)acc;
+    return fq30_redc(T);
+}
+
+// ---- lazy additive operations (no modular reduction; callers track bounds) -----------------------
+// a + b, normalised.  Value a + b must be < 2^390.
+TY_HD Fq30 fq30_add_lazy(const Fq30& a, const Fq30& b) {
+    Fq30 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const uint32_t s = a.v[i] + b.v[i] + c;
+        r.v[i] = s & FQ30_MASK;
+        c = s >> 30;
+    }
+    return r;
+}
+// k*a for k = 2 or 3, normalised.
+template <int K>
+TY_HD Fq30 fq30_mulk_lazy(const Fq30& a) {
+    Fq30 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const uint32_t s = a.v[i] * (uint32_t)K + c;  // < 3 * 2^30 + 3 < 2^32
+        r.v[i] = s & FQ30_MASK;
+        c = s >> 30;
+    }
+    return r;
+}
+// a - b + K p, normalised.  Requires b <= K p (so the value is >= 0) and a + K p < 2^390.
+template <int K>
+TY_HD Fq30 fq30_sub_lazy(const Fq30& a, const Fq30& b) {
+    Fq30 r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int32_t s = (int32_t)(a.v[i] + fq30_kp(K, i)) + c - (int32_t)b.v[i];
+        r.v[i] = (uint32_t)s & FQ30_MASK;
+        c = s >> 30;
+    }
+    return r;
+}
+// a - b - c + K p, normalised.  Requires b + c <= K p.
+template <int K>
+TY_HD Fq30 fq30_sub2_lazy(const Fq30& a, const Fq30& b, const Fq30& cc) {
+    Fq30 r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int32_t s = (int32_t)(a.v[i] + fq30_kp(K, i)) + c - (int32_t)b.v[i] - (int32_t)cc.v[i];
+        r.v[i] = (uint32_t)s & FQ30_MASK;
+        c = s >> 30;
+    }
+    return r;
+}
+// K p - a  (a <= K p)
+template <int K>
+TY_HD Fq30 fq30_neg_lazy(const Fq30& a) {
+    return fq30_sub_lazy<K>(fq30_zero(), a);
+}
+
+// ---- exact predicates / canonical form ------------------------------------------------------------
+// a == 0 mod p for a normalised a < 2p
+TY_HD bool fq30_is_zero_mod(const Fq30& a) {
+    uint32_t z = 0, q = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        z |= a.v[i];
+        q |= a.v[i] ^ fq30_kp(1, i);
+    }
+    return z == 0 || q == 0;
+}
+TY_HD bool fq30_is_zero_exact(const Fq30& a) {
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) z |= a.v[i];
+    return z == 0;
+}
+// r = a - K p if that is >= 0 else a
+template <int K>
+TY_HD void fq30_cond_sub(Fq30& a) {
+    uint32_t d[13];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int32_t s = (int32_t)a.v[i] + c - (int32_t)fq30_kp(K, i);
+        d[i] = (uint32_t)s & FQ30_MASK;
+        c = s >> 30;
+    }
+    if (c >= 0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) a.v[i] = d[i];
+    }
+}
+// canonical representative in [0, p) of a normalised a < 8p
+TY_HD Fq30 fq30_canon(const Fq30& a) {
+    Fq30 r = a;
+    fq30_cond_sub<4>(r);
+    fq30_cond_sub<2>(r);
+    fq30_cond_sub<1>(r);
+    return r;
+}
+
+// ---- packed 12 x 32-bit memory form ------------------------------------------------------------------
+TY_HD Fq30 fq30_unpack(const uint32_t (&w)[12]) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int bit = 30 * i, wi = bit >> 5, sh = bit & 31;
+        uint32_t x = w[wi] >> sh;
+        if (sh > 2 && wi + 1 < 12) x |= w[wi + 1] << (32 - sh);
+        r.v[i] = x & FQ30_MASK;
+    }
+    return r;
+}
+// value must be < 2^384
+TY_HD void fq30_pack(const Fq30& a, uint32_t (&w)[12]) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int bit = 32 * j, li = bit / 30, off = bit % 30;
+        uint32_t x = a.v[li] >> off;
+        if (li + 1 < 13) x |= a.v[li + 1] << (30 - off);
+        if (off > 28 && li + 2 < 13) x |= a.v[li + 2] << (60 - off);
+        w[j] = x;
+    }
+}
+
+// arkworks residue (12 words, x*2^384 mod p, canonical) -> internal x*2^390, canonical
+TY_HD Fq30 fq30_from_ark(const uint32_t (&w)[12]) {
+    Fq30 c;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) c.v[i] = fq30_cin_limb(i);
+    return fq30_canon(fq30_mul(fq30_unpack(w), c));
+}
+// internal (< 8p) -> arkworks residue words, canonical
+TY_HD void fq30_to_ark(const Fq30& a, uint32_t (&w)[12]) {
+    Fq30 c;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) c.v[i] = fq30_cout_limb(i);
+    fq30_pack(fq30_canon(fq30_mul(a, c)), w);
+}
+
+// a^-1 (Fermat, a^(p-2)); input < 2p, output < 1.01 p.  0 -> 0.
+TY_HD Fq30 fq30_inv(const Fq30& a) {
+    // exponent p - 2 as 32-bit words (little endian)
+    constexpr uint32_t e[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+    Fq30 acc = fq30_one();
+    bool started = false;
+    for (int w = 11; w >= 0; --w) {
+        for (int b = 31; b >= 0; --b) {
+            if (started) acc = fq30_sqr(acc);
+            if ((e[w] >> b) & 1) {
+                acc = started ? fq30_mul(acc, a) : a;
+                started = true;
+            }
+        }
+    }
+    return acc;
+}
+
+}  // namespace ty

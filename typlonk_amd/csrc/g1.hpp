@@ -8,33 +8,38 @@
 // returns its unique canonical affine form, so the choice of coordinates cannot change a single
 // output bit -- provided every exceptional case (identity operand, P+P, P+(-P)) is handled, which
 // the functions below do explicitly.
+//
+// Field values are lazily reduced (fq30.hpp).  Invariants of a stored XYZZ point, in units of p:
+//     X < 5.1    Y < 3.2    ZZ, ZZZ < 1.1      (all < 8p < 2^384, so they pack into 12 words)
+// Affine points have canonical coordinates (< p).  Each line below carries the bound of its
+// result; "m(A,B)" = 1 + A*B/630 is the bound of a Montgomery product of inputs < A p and < B p.
 #pragma once
-#include "ff.hpp"
+#include "fq30.hpp"
 
 namespace ty {
 
-// Affine base point as stored on the device: identity is encoded (0, 0), which is not on the
-// curve (0 != 0 + 4).  The C-ABI's separate `inf` flag byte is folded into this form at upload.
+// Affine point; identity is encoded (0, 0), which is not on the curve (0 != 0 + 4).  The C-ABI's
+// separate `inf` flag byte is folded into this form at upload.
 struct G1Affine {
-    Fq x, y;
-    TY_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    Fq30 x, y;  // canonical, Montgomery R = 2^390
+    TY_HD bool is_inf() const { return fq30_is_zero_exact(x) && fq30_is_zero_exact(y); }
     static TY_HD G1Affine inf() {
         G1Affine r;
-        r.x = Fq::zero();
-        r.y = Fq::zero();
+        r.x = fq30_zero();
+        r.y = fq30_zero();
         return r;
     }
 };
 
 struct G1Xyzz {
-    Fq x, y, zz, zzz;
-    TY_HD bool is_inf() const { return zz.is_zero(); }
+    Fq30 x, y, zz, zzz;
+    TY_HD bool is_inf() const { return fq30_is_zero_mod(zz); }
     static TY_HD G1Xyzz inf() {
         G1Xyzz r;
-        r.x = Fq::one();
-        r.y = Fq::one();
-        r.zz = Fq::zero();
-        r.zzz = Fq::zero();
+        r.x = fq30_one();
+        r.y = fq30_one();
+        r.zz = fq30_zero();
+        r.zzz = fq30_zero();
         return r;
     }
     static TY_HD G1Xyzz from_affine(const G1Affine& p) {
@@ -42,24 +47,24 @@ struct G1Xyzz {
         G1Xyzz r;
         r.x = p.x;
         r.y = p.y;
-        r.zz = Fq::one();
-        r.zzz = Fq::one();
+        r.zz = fq30_one();
+        r.zzz = fq30_one();
         return r;
     }
 };
 
-// 2*(x, y) for an affine non-identity point  (dbl-2008-s-1 with ZZ = ZZZ = 1)
-TY_HD G1Xyzz g1_dbl_affine(const Fq& x, const Fq& y) {
+// 2*(x, y) for an affine non-identity point, x, y < 1.1  (dbl-2008-s-1 with ZZ = ZZZ = 1)
+TY_HD G1Xyzz g1_dbl_affine(const Fq30& x, const Fq30& y) {
     G1Xyzz r;
-    if (y.is_zero()) return G1Xyzz::inf();  // order-2 point; none on G1, kept for totality
-    Fq u = fe_dbl(y);
-    Fq v = fe_sqr(u);
-    Fq w = fe_mul(u, v);
-    Fq s = fe_mul(x, v);
-    Fq xx = fe_sqr(x);
-    Fq m = fe_add(fe_dbl(xx), xx);
-    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
-    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, y));
+    const Fq30 u = fq30_mulk_lazy<2>(y);                               // < 2.2
+    const Fq30 v = fq30_sqr(u);                                        // m(2.2,2.2) < 1.01
+    if (fq30_is_zero_mod(v)) return G1Xyzz::inf();                     // y = 0: order-2 point (none on G1)
+    const Fq30 w = fq30_mul(u, v);                                     // < 1.01
+    const Fq30 s = fq30_mul(x, v);                                     // < 1.01
+    const Fq30 m = fq30_mulk_lazy<3>(fq30_sqr(x));                     // 3 * 1.01 < 3.1
+    r.x = fq30_sub_lazy<3>(fq30_sqr(m), fq30_mulk_lazy<2>(s));         // m(3.1,3.1) + 3 < 4.1   (2s < 2.1 <= 3)
+    const Fq30 t = fq30_sub_lazy<5>(s, r.x);                           // 1.01 + 5 < 6.1         (X3 < 4.1 <= 5)
+    r.y = fq30_sub_lazy<2>(fq30_mul(m, t), fq30_mul(w, y));            // m(3.1,6.1) + 2 < 3.1   (w*y < 1.01 <= 2)
     r.zz = v;
     r.zzz = w;
     return r;
@@ -67,58 +72,59 @@ TY_HD G1Xyzz g1_dbl_affine(const Fq& x, const Fq& y) {
 
 // 2*P  (dbl-2008-s-1)
 TY_HD G1Xyzz g1_dbl(const G1Xyzz& p) {
-    if (p.is_inf() || p.y.is_zero()) return G1Xyzz::inf();
+    if (p.is_inf()) return G1Xyzz::inf();
     G1Xyzz r;
-    Fq u = fe_dbl(p.y);
-    Fq v = fe_sqr(u);
-    Fq w = fe_mul(u, v);
-    Fq s = fe_mul(p.x, v);
-    Fq xx = fe_sqr(p.x);
-    Fq m = fe_add(fe_dbl(xx), xx);
-    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
-    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, p.y));
-    r.zz = fe_mul(v, p.zz);
-    r.zzz = fe_mul(w, p.zzz);
+    const Fq30 u = fq30_mulk_lazy<2>(p.y);                             // < 6.4
+    const Fq30 v = fq30_sqr(u);                                        // m(6.4,6.4) < 1.07
+    if (fq30_is_zero_mod(v)) return G1Xyzz::inf();
+    const Fq30 w = fq30_mul(u, v);                                     // m(6.4,1.07) < 1.02
+    const Fq30 s = fq30_mul(p.x, v);                                   // m(5.1,1.07) < 1.01
+    const Fq30 m = fq30_mulk_lazy<3>(fq30_sqr(p.x));                   // 3 * m(5.1,5.1) < 3.2
+    r.x = fq30_sub_lazy<3>(fq30_sqr(m), fq30_mulk_lazy<2>(s));         // m(3.2,3.2) + 3 < 4.1
+    const Fq30 t = fq30_sub_lazy<5>(s, r.x);                           // < 6.1
+    r.y = fq30_sub_lazy<2>(fq30_mul(m, t), fq30_mul(w, p.y));          // m(3.2,6.1) + 2 < 3.1   (w*Y < 1.01)
+    r.zz = fq30_mul(v, p.zz);                                          // < 1.01
+    r.zzz = fq30_mul(w, p.zzz);                                        // < 1.01
     return r;
 }
 
-// acc += (qx, qy)   mixed addition, madd-2008-s; the affine operand must not be the identity
-// (callers test G1Affine::is_inf first).
-TY_HD void g1_madd_xy(G1Xyzz& acc, const Fq& qx, const Fq& qy) {
+// acc += (qx, qy)   mixed addition, madd-2008-s; qx, qy < 1.1; the affine operand must not be the
+// identity (callers test G1Affine::is_inf first).
+TY_HD void g1_madd_xy(G1Xyzz& acc, const Fq30& qx, const Fq30& qy) {
     if (acc.is_inf()) {
         acc.x = qx;
         acc.y = qy;
-        acc.zz = Fq::one();
-        acc.zzz = Fq::one();
+        acc.zz = fq30_one();
+        acc.zzz = fq30_one();
         return;
     }
-    Fq u2 = fe_mul(qx, acc.zz);
-    Fq s2 = fe_mul(qy, acc.zzz);
-    Fq p = fe_sub(u2, acc.x);
-    Fq r = fe_sub(s2, acc.y);
-    if (p.is_zero()) {
-        if (r.is_zero()) {
+    const Fq30 u2 = fq30_mul(qx, acc.zz);                              // < 1.01
+    const Fq30 s2 = fq30_mul(qy, acc.zzz);                             // < 1.01
+    const Fq30 p = fq30_sub_lazy<6>(u2, acc.x);                        // 1.01 + 6 < 7.1   (X1 < 5.1 <= 6)
+    const Fq30 r = fq30_sub_lazy<4>(s2, acc.y);                        // 1.01 + 4 < 5.1   (Y1 < 3.2 <= 4)
+    const Fq30 pp = fq30_sqr(p);                                       // m(7.1,7.1) < 1.09
+    if (fq30_is_zero_mod(pp)) {                                        // P = 0  <=>  same x
+        if (fq30_is_zero_mod(fq30_sqr(r))) {                           // and same y: doubling
             acc = g1_dbl_affine(qx, qy);
         } else {
             acc = G1Xyzz::inf();
         }
         return;
     }
-    Fq pp = fe_sqr(p);
-    Fq ppp = fe_mul(p, pp);
-    Fq q = fe_mul(acc.x, pp);
-    Fq x3 = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(q));
-    Fq y3 = fe_sub(fe_mul(r, fe_sub(q, x3)), fe_mul(acc.y, ppp));
+    const Fq30 ppp = fq30_mul(p, pp);                                  // m(7.1,1.09) < 1.02
+    const Fq30 q = fq30_mul(acc.x, pp);                                // m(5.1,1.09) < 1.01
+    const Fq30 x3 = fq30_sub2_lazy<4>(fq30_sqr(r), ppp, fq30_mulk_lazy<2>(q));  // m(5.1,5.1) + 4 < 5.1  (ppp + 2q < 3.1 <= 4)
+    const Fq30 t = fq30_sub_lazy<6>(q, x3);                            // 1.01 + 6 < 7.1
+    acc.y = fq30_sub_lazy<2>(fq30_mul(r, t), fq30_mul(acc.y, ppp));    // m(5.1,7.1) + 2 < 3.1   (Y1*ppp < 1.01)
     acc.x = x3;
-    acc.y = y3;
-    acc.zz = fe_mul(acc.zz, pp);
-    acc.zzz = fe_mul(acc.zzz, ppp);
+    acc.zz = fq30_mul(acc.zz, pp);                                     // < 1.01
+    acc.zzz = fq30_mul(acc.zzz, ppp);                                  // < 1.01
 }
 
 // acc += (neg ? -q : q)
 TY_HD void g1_madd(G1Xyzz& acc, const G1Affine& q, bool neg) {
     if (q.is_inf()) return;
-    Fq qy = neg ? fe_neg(q.y) : q.y;
+    const Fq30 qy = neg ? fq30_neg_lazy<1>(q.y) : q.y;                 // p - y <= p
     g1_madd_xy(acc, q.x, qy);
 }
 
@@ -126,44 +132,39 @@ TY_HD void g1_madd(G1Xyzz& acc, const G1Affine& q, bool neg) {
 TY_HD G1Xyzz g1_add(const G1Xyzz& a, const G1Xyzz& b) {
     if (a.is_inf()) return b;
     if (b.is_inf()) return a;
-    Fq u1 = fe_mul(a.x, b.zz);
-    Fq u2 = fe_mul(b.x, a.zz);
-    Fq s1 = fe_mul(a.y, b.zzz);
-    Fq s2 = fe_mul(b.y, a.zzz);
-    Fq p = fe_sub(u2, u1);
-    Fq r = fe_sub(s2, s1);
-    if (p.is_zero()) {
-        if (r.is_zero()) return g1_dbl(a);
+    const Fq30 u1 = fq30_mul(a.x, b.zz);                               // m(5.1,1.1) < 1.01
+    const Fq30 u2 = fq30_mul(b.x, a.zz);                               // < 1.01
+    const Fq30 s1 = fq30_mul(a.y, b.zzz);                              // < 1.01
+    const Fq30 s2 = fq30_mul(b.y, a.zzz);                              // < 1.01
+    const Fq30 p = fq30_sub_lazy<2>(u2, u1);                           // < 3.1
+    const Fq30 r = fq30_sub_lazy<2>(s2, s1);                           // < 3.1
+    const Fq30 pp = fq30_sqr(p);                                       // < 1.02
+    if (fq30_is_zero_mod(pp)) {
+        if (fq30_is_zero_mod(fq30_sqr(r))) return g1_dbl(a);
         return G1Xyzz::inf();
     }
-    Fq pp = fe_sqr(p);
-    Fq ppp = fe_mul(p, pp);
-    Fq q = fe_mul(u1, pp);
+    const Fq30 ppp = fq30_mul(p, pp);                                  // < 1.01
+    const Fq30 q = fq30_mul(u1, pp);                                   // < 1.01
     G1Xyzz o;
-    o.x = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(q));
-    o.y = fe_sub(fe_mul(r, fe_sub(q, o.x)), fe_mul(s1, ppp));
-    o.zz = fe_mul(fe_mul(a.zz, b.zz), pp);
-    o.zzz = fe_mul(fe_mul(a.zzz, b.zzz), ppp);
+    o.x = fq30_sub2_lazy<4>(fq30_sqr(r), ppp, fq30_mulk_lazy<2>(q));   // m(3.1,3.1) + 4 < 5.1
+    const Fq30 t = fq30_sub_lazy<6>(q, o.x);                           // < 7.1
+    o.y = fq30_sub_lazy<2>(fq30_mul(r, t), fq30_mul(s1, ppp));         // m(3.1,7.1) + 2 < 3.1
+    o.zz = fq30_mul(fq30_mul(a.zz, b.zz), pp);                         // < 1.01
+    o.zzz = fq30_mul(fq30_mul(a.zzz, b.zzz), ppp);                     // < 1.01
     return o;
 }
 
-TY_HD G1Xyzz g1_neg(const G1Xyzz& a) {
-    G1Xyzz r = a;
-    r.y = fe_neg(a.y);
-    return r;
-}
-
-// Canonical affine form (one field inversion).  Identity -> (0, 0) (device encoding).
+// Canonical affine form (one field inversion).  Identity -> (0, 0).
 TY_HD G1Affine g1_to_affine(const G1Xyzz& p) {
     if (p.is_inf()) return G1Affine::inf();
-    Fq t = fe_inv(fe_mul(p.zz, p.zzz));
+    const Fq30 t = fq30_inv(fq30_mul(p.zz, p.zzz));
     G1Affine r;
-    r.x = fe_mul(p.x, fe_mul(t, p.zzz));  // X / ZZ
-    r.y = fe_mul(p.y, fe_mul(t, p.zz));   // Y / ZZZ
+    r.x = fq30_canon(fq30_mul(p.x, fq30_mul(t, p.zzz)));  // X / ZZ
+    r.y = fq30_canon(fq30_mul(p.y, fq30_mul(t, p.zz)));   // Y / ZZZ
     return r;
 }
 
-// k * P for a small unsigned k (bucket-reduction segment offsets), double-and-add.
+// k * P for a small unsigned k, double-and-add.
 TY_HD G1Xyzz g1_mul_small(const G1Xyzz& p, uint32_t k) {
     G1Xyzz acc = G1Xyzz::inf();
     for (int b = 31; b >= 0; --b) {

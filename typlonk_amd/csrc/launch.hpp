@@ -13,7 +13,7 @@ constexpr int MSM_SEG = 8;            // buckets per reduce thread
 
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s);
 
-void launch_mark_inf(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);
+void launch_convert_points(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);
 void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t* keys,
                        uint32_t* counts, hipStream_t s);
 void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor,

@@ -24,20 +24,20 @@ constexpr uint32_t MSM_SKIP = 0xffffffffu;
 constexpr int MSM_THREADS = 256;
 constexpr int MSM_ACC_THREADS = 64;
 
-__device__ __forceinline__ Fq ld_fq(const uint32_t* p) {
+// HBM form of a field element: 12 packed 32-bit words (fq30.hpp); three 16-byte accesses.
+__device__ __forceinline__ Fq30 ld_fq(const uint32_t* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1], c = q[2];
-    Fq r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w;
-    return r;
+    const uint4 a = q[0], b = q[1], c = q[2];
+    const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    return fq30_unpack(w);
 }
-__device__ __forceinline__ void st_fq(uint32_t* p, const Fq& r) {
+__device__ __forceinline__ void st_fq(uint32_t* p, const Fq30& r) {
+    uint32_t w[12];
+    fq30_pack(r, w);
     uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-    q[2] = make_uint4(r.v[8], r.v[9], r.v[10], r.v[11]);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    q[2] = make_uint4(w[8], w[9], w[10], w[11]);
 }
 __device__ __forceinline__ G1Affine ld_affine(const uint32_t* pts, uint64_t idx) {
     const uint32_t* p = pts + idx * 24;
@@ -62,6 +62,5 @@ __device__ __forceinline__ void st_xyzz(uint32_t* b, uint64_t idx, const G1Xyzz&
     st_fq(p + 24, r.zz);
     st_fq(p + 36, r.zzz);
 }
-
 
 }  // namespace ty

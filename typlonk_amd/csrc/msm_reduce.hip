@@ -7,7 +7,7 @@ namespace ty {
 __device__ __forceinline__ G1Xyzz shfl_xor_point(const G1Xyzz& p, int mask) {
     G1Xyzz r;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < 13; ++i) {
         r.x.v[i] = __shfl_xor(p.x.v[i], mask);
         r.y.v[i] = __shfl_xor(p.y.v[i], mask);
         r.zz.v[i] = __shfl_xor(p.zz.v[i], mask);

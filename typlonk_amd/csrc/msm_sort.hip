@@ -5,11 +5,21 @@
 
 namespace ty {
 
-// Fold the C-ABI's separate infinity flags into the device encoding (0, 0).
-__global__ void msm_mark_inf_kernel(uint32_t* pts, const uint8_t* inf, uint64_t n) {
+// SRS upload: arkworks residues (R = 2^384, 12 words per coordinate) -> the internal packed form
+// (R = 2^390, canonical); the C-ABI's separate infinity flags fold into the (0, 0) encoding.
+__global__ void msm_convert_points_kernel(uint32_t* pts, const uint8_t* inf, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !inf[i]) return;
-    for (int w = 0; w < 24; ++w) pts[i * 24 + w] = 0;
+    if (i >= n) return;
+    uint32_t* p = pts + i * 24;
+    if (inf && inf[i]) {
+        for (int w = 0; w < 24; ++w) p[w] = 0;
+        return;
+    }
+    uint32_t w[12];
+    for (int k = 0; k < 2; ++k) {
+        for (int j = 0; j < 12; ++j) w[j] = p[12 * k + j];
+        st_fq(p + 12 * k, fq30_from_ark(w));
+    }
 }
 
 // bits [o, o+c) of a 256-bit little-endian integer, c <= 24
@@ -150,8 +160,8 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const uint32_t
 }
 
 
-void launch_mark_inf(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(msm_mark_inf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pts, inf, n);
+void launch_convert_points(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(msm_convert_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pts, inf, n);
 }
 void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t* keys,
                        uint32_t* counts, hipStream_t s) {

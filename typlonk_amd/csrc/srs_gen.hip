@@ -9,7 +9,7 @@ namespace ty {
 
 struct SrsGenArgs {
     Fr s;
-    Fq gx, gy;
+    Fq30 gx, gy;
     uint64_t start, n;
     uint32_t* pts;
 };
@@ -41,12 +41,12 @@ __global__ __launch_bounds__(64) void srs_generate_kernel(SrsGenArgs a) {
 void launch_srs_generate(const Fr& s, uint64_t start, uint64_t n, uint32_t* pts, hipStream_t st) {
     SrsGenArgs a;
     a.s = s;
-    // G1 generator, Montgomery form (ark-bls12-381 G1_GENERATOR_X / _Y)
-    const uint32_t gx[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
-                             0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
-    const uint32_t gy[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
-                             0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
-    for (int i = 0; i < 12; ++i) {
+    // G1 generator in the internal form (x * 2^390 mod p as 30-bit digits)
+    const uint32_t gx[13] = {0x14d1b01cu, 0x143790fdu, 0x34ffd633u, 0x1bc687f8u, 0x3e2228c0u, 0x04f86aa1u, 0x298df978u,
+                             0x2e28c656u, 0x1b36e719u, 0x3ed397edu, 0x2f68adadu, 0x096840ceu, 0x00082ebcu};
+    const uint32_t gy[13] = {0x39d1f18cu, 0x0d03d50cu, 0x10f63b65u, 0x3231b0b8u, 0x2e87afadu, 0x02eceb19u, 0x258480d0u,
+                             0x31f25b61u, 0x08856e09u, 0x1fef8f3eu, 0x1a3501cbu, 0x1d6e0ad8u, 0x0016f1c9u};
+    for (int i = 0; i < 13; ++i) {
         a.gx.v[i] = gx[i];
         a.gy.v[i] = gy[i];
     }
