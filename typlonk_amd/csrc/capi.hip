@@ -54,7 +54,7 @@ struct typlonk_ctx {
     std::map<uint32_t, SrsEntry> srs;
     uint32_t next_srs = 1;
     // MSM workspaces (grow-only)
-    DevBuf scal, keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b;
+    DevBuf scal, keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist;
     // NTT
     DevBuf ntt_scratch, ntt_io;
     std::map<std::string, Table> tables;
@@ -425,6 +425,8 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     if ((rc = ensure(ctx, ctx->cursor, nb * 4))) return rc;
     if ((rc = ensure(ctx, ctx->blocksums, (size_t)scan_blocks * 4))) return rc;
     if ((rc = ensure(ctx, ctx->buckets, nb * 192))) return rc;
+    if ((rc = ensure(ctx, ctx->order, nb * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ohist, 512 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->part_a, (size_t)nodes * 192))) return rc;
     if ((rc = ensure(ctx, ctx->part_b, (size_t)nodes * 192))) return rc;
 
@@ -449,12 +451,16 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
         launch_scan(counts, nb, blocksums, offsets, cursor, s);
     }
     {
+        StageTimer st(ctx, "msm_order");
+        launch_bucket_order(counts, (uint32_t)nb, (uint32_t*)ctx->ohist.p, (uint32_t*)ctx->order.p, s);
+    }
+    {
         StageTimer st(ctx, "msm_scatter");
         launch_msm_scatter(keys, (uint64_t)m, total, cursor, sorted, s);
     }
     {
         StageTimer st(ctx, "msm_accum");
-        launch_msm_accum(srs.d_points, offsets, sorted, (uint32_t)nb, buckets, s);
+        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ctx->order.p, (uint32_t)nb, buckets, s);
     }
     uint32_t* cur = pa;
     uint32_t* other = pb;
@@ -543,7 +549,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
     for (DevBuf* b : {&ctx->scal, &ctx->keys, &ctx->sorted, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->blocksums,
-                      &ctx->buckets, &ctx->part_a, &ctx->part_b, &ctx->ntt_scratch, &ctx->ntt_io})
+                      &ctx->buckets, &ctx->part_a, &ctx->part_b, &ctx->order, &ctx->ohist, &ctx->ntt_scratch, &ctx->ntt_io})
         release(*b);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -149,6 +149,185 @@ __global__ __launch_bounds__(256) void scan_finish_kernel(const uint32_t* in, ui
     }
 }
 
+// ---- segmented counting sort (no global atomics) ------------------------------------------------------
+// Bucket id = (window j, bucket-in-window b).  Level 1 partitions the W*m entries into
+// nseg = W << hb segments keyed by (j, b >> lb); level 2 sorts every segment by the low lb <= 8 bits
+// inside one workgroup.  Level 1 is the classic radix-sort scheme: every workgroup histograms its
+// chunk of MSM_CHUNK scalars in LDS and publishes the column blk_hist[seg * nblk + blk]; one
+// exclusive scan over that matrix gives each (segment, workgroup) its private output range, so
+// the scatter needs only LDS atomics (for the rank inside the workgroup).
+// Level-1 entry: idx (23 bits) | sign << 23 | (b & (2^lb - 1)) << 24     (m <= 2^23)
+constexpr int MSM_CHUNK = 2048;  // scalars per workgroup = 8 per thread
+
+struct MsmShape {
+    uint32_t c, W, top_v, hb, lb, nseg, nblk;
+};
+
+// canonical scalar -> (bucket-in-window, sign) for every window, in window order
+template <class F>
+__device__ __forceinline__ void msm_for_each_digit(const uint32_t (&v)[8], const MsmShape& sh, uint32_t i, F&& emit) {
+    const uint32_t B = 1u << (sh.c - 1);
+    uint32_t carry = 0;
+    for (uint32_t j = 0; j < sh.W; ++j) {
+        const uint32_t o = j * sh.c;
+        uint32_t d = (o < 256 ? msm_bits(v, o, sh.c) : 0u) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (d > B) {
+            d = (1u << sh.c) - d;
+            neg = 1;
+            carry = 1;
+        }
+        if (d != 0) {
+            const uint32_t b = (j + 1 == sh.W) ? ((d - 1) << sh.top_v) + (i & ((1u << sh.top_v) - 1)) : d - 1;
+            emit(j, b, neg);
+        }
+    }
+}
+
+__device__ __forceinline__ void msm_load_canon(const Fr* scalars, uint64_t i, uint32_t (&out)[8]) {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i);
+    const uint4 a = sp[0], b = sp[1];
+    Fr s;
+    s.v[0] = a.x; s.v[1] = a.y; s.v[2] = a.z; s.v[3] = a.w;
+    s.v[4] = b.x; s.v[5] = b.y; s.v[6] = b.z; s.v[7] = b.w;
+    s = fe_from_mont(s);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = s.v[k];
+}
+
+__global__ __launch_bounds__(256) void msm_seg_hist_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
+                                                           uint32_t* blk_hist) {
+    extern __shared__ uint32_t seg_h[];
+    for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) seg_h[s] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * MSM_CHUNK;
+    for (int e = 0; e < MSM_CHUNK / 256; ++e) {
+        const uint64_t i = base + threadIdx.x + 256 * e;
+        if (i < m) {
+            uint32_t v[8];
+            msm_load_canon(scalars, i, v);
+            msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t) {
+                atomicAdd(&seg_h[(j << sh.hb) | (b >> sh.lb)], 1u);
+            });
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) blk_hist[(uint64_t)s * sh.nblk + blockIdx.x] = seg_h[s];
+}
+
+__global__ __launch_bounds__(256) void msm_seg_scatter_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
+                                                              const uint32_t* blk_base, uint32_t* entries) {
+    extern __shared__ uint32_t seg_sm[];
+    uint32_t* cur = seg_sm;             // running position of this workgroup inside each segment
+    for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) cur[s] = blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * MSM_CHUNK;
+    const uint32_t lmask = (1u << sh.lb) - 1;
+    for (int e = 0; e < MSM_CHUNK / 256; ++e) {
+        const uint64_t i = base + threadIdx.x + 256 * e;
+        if (i < m) {
+            uint32_t v[8];
+            msm_load_canon(scalars, i, v);
+            msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
+                const uint32_t pos = atomicAdd(&cur[(j << sh.hb) | (b >> sh.lb)], 1u);
+                entries[pos] = (uint32_t)i | (neg << 23) | ((b & lmask) << 24);
+            });
+        }
+    }
+}
+
+// one workgroup per segment: count by low bits, local exclusive scan -> bucket counts/offsets,
+// then the final scatter.  The segment is read twice from L2; only a 256-bin histogram lives in LDS,
+// so any segment length works.
+__global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __restrict__ entries,
+                                                           const uint32_t* __restrict__ blk_base, MsmShape sh,
+                                                           uint32_t total_slot, uint32_t* counts, uint32_t* offsets,
+                                                           uint32_t* sorted) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t pref[256];
+    const uint32_t s = blockIdx.x;
+    const uint32_t start = blk_base[(uint64_t)s * sh.nblk];
+    const uint32_t end = (s + 1 < sh.nseg) ? blk_base[(uint64_t)(s + 1) * sh.nblk] : blk_base[total_slot];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t e = start + threadIdx.x; e < end; e += 256) atomicAdd(&hist[entries[e] >> 24], 1u);
+    __syncthreads();
+    const uint32_t mine = hist[threadIdx.x];
+    pref[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t t = (int)threadIdx.x >= off ? pref[threadIdx.x - off] : 0;
+        __syncthreads();
+        pref[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const uint32_t excl = pref[threadIdx.x] - mine;
+    __syncthreads();
+    pref[threadIdx.x] = excl;
+    hist[threadIdx.x] = 0;
+    const uint32_t nlow = 1u << sh.lb;
+    if (threadIdx.x < nlow) {
+        const uint32_t bucket = s * nlow + threadIdx.x;
+        counts[bucket] = mine;
+        offsets[bucket] = start + excl;
+        if (s + 1 == sh.nseg && threadIdx.x + 1 == nlow) offsets[bucket + 1] = end;
+    }
+    __syncthreads();
+    for (uint32_t e = start + threadIdx.x; e < end; e += 256) {
+        const uint32_t v = entries[e];
+        const uint32_t b = v >> 24;
+        const uint32_t r = atomicAdd(&hist[b], 1u);
+        sorted[start + pref[b] + r] = (v & 0x7fffffu) | ((v & 0x800000u) << 8);
+    }
+}
+
+// ---- bucket schedule: order[] = bucket ids sorted by population, largest first --------------------
+// A wave's 64 lanes run their buckets in lock step, so its time is the LARGEST of its 64 bucket
+// sizes; handing each wave buckets of (nearly) equal size removes that imbalance.  Counting sort on
+// min(count, 255): LDS-privatised histogram per block, one global atomic per (block, bin).
+__global__ __launch_bounds__(256) void order_hist_kernel(const uint32_t* counts, uint32_t n, uint32_t* hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g < n) atomicAdd(&h[min(counts[g], 255u)], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// single block: base[s] = number of buckets with a larger size key (descending order)
+__global__ __launch_bounds__(256) void order_scan_kernel(const uint32_t* hist, uint32_t* base) {
+    __shared__ uint32_t buf[256];
+    const uint32_t k = 255 - threadIdx.x;  // thread t handles size key 255 - t
+    const uint32_t v = hist[k];
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    base[k] = buf[threadIdx.x] - v;
+}
+__global__ __launch_bounds__(256) void order_scatter_kernel(const uint32_t* counts, uint32_t n, uint32_t* base,
+                                                            uint32_t* order) {
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t blk[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = 0, rank = 0;
+    if (g < n) {
+        key = min(counts[g], 255u);
+        rank = atomicAdd(&h[key], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) blk[threadIdx.x] = atomicAdd(&base[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (g < n) order[blk[key] + rank] = g;
+}
+
 __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const uint32_t* keys, uint64_t m, uint64_t total,
                                                                   uint32_t* cursor, uint32_t* sorted) {
     const uint64_t e = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
@@ -174,6 +353,44 @@ void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint3
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblk), dim3(256), 0, s, counts, n, block_sums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, nblk);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(nblk), dim3(256), 0, s, counts, n, block_sums, offsets, cursor);
+}
+// plain exclusive scan of n counters into out[0..n] (out[n] = total); scratch: ceil(n/2048) u32
+void launch_exclusive_scan(const uint32_t* in, uint64_t n, uint32_t* block_sums, uint32_t* out, uint32_t* out2,
+                           hipStream_t s) {
+    const uint32_t nblk = (uint32_t)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblk), dim3(256), 0, s, in, n, block_sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, nblk);
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(nblk), dim3(256), 0, s, in, n, block_sums, out, out2);
+}
+
+void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
+                        uint32_t* blk_hist, uint32_t* blk_base, uint32_t* scan_scratch, uint32_t* entries,
+                        uint32_t* counts, uint32_t* offsets, uint32_t* sorted, hipStream_t s) {
+    MsmShape sh;
+    sh.c = c;
+    sh.W = W;
+    sh.top_v = top_v;
+    sh.hb = hb;
+    sh.lb = c - 1 - hb;
+    sh.nseg = W << hb;
+    sh.nblk = (uint32_t)((m + MSM_CHUNK - 1) / MSM_CHUNK);
+    const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
+    hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(256), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
+                       blk_hist);
+    launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, s);
+    hipLaunchKernelGGL(msm_seg_scatter_kernel, dim3(sh.nblk), dim3(256), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
+                       blk_base, entries);
+    hipLaunchKernelGGL(msm_seg_sort_kernel, dim3(sh.nseg), dim3(256), 0, s, entries, blk_base, sh, (uint32_t)nmat, counts,
+                       offsets, sorted);
+}
+
+void launch_bucket_order(const uint32_t* counts, uint32_t n, uint32_t* hist512, uint32_t* order, hipStream_t s) {
+    // hist512: 512 u32 of scratch (histogram + running bases)
+    hipMemsetAsync(hist512, 0, 512 * sizeof(uint32_t), s);
+    const uint32_t nblk = (n + 255) / 256;
+    hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist512);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist512, hist512 + 256);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist512 + 256, order);
 }
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
                         hipStream_t s) {
