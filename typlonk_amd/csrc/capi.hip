@@ -54,7 +54,7 @@ struct typlonk_ctx {
     std::map<uint32_t, SrsEntry> srs;
     uint32_t next_srs = 1;
     // MSM workspaces (grow-only)
-    DevBuf scal, keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist;
+    DevBuf scal, keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist, blk_hist, blk_base;
     // NTT
     DevBuf ntt_scratch, ntt_io;
     std::map<std::string, Table> tables;
@@ -63,6 +63,7 @@ struct typlonk_ctx {
     std::vector<ProfStage> prof;
     std::vector<std::pair<const char*, float>> prof_result;
     int msm_c_override = 0;
+    bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
 };
 
 namespace {
@@ -441,22 +442,41 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     uint32_t* pb = (uint32_t*)ctx->part_b.p;
     hipStream_t s = ctx->stream;
 
-    {
-        StageTimer st(ctx, "msm_digits");
-        HIPCHK(hipMemsetAsync(counts, 0, nb * 4, s));
-        launch_msm_digits(d_scalars, (uint64_t)m, c, W, top_v, keys, counts, s);
-    }
-    {
-        StageTimer st(ctx, "msm_scan");
-        launch_scan(counts, nb, blocksums, offsets, cursor, s);
+    // segmented sort shape: hb high bucket bits pick the segment, lb <= 8 low bits are sorted in LDS
+    uint32_t lgm = 0;
+    while (((uint64_t)1 << lgm) < m) ++lgm;
+    int hb = std::max<int>((int)c - 9, (int)lgm - 13);
+    hb = std::max(0, std::min<int>(hb, (int)c - 1));
+    const uint64_t nseg = (uint64_t)W << hb;
+    const uint64_t nblk = (m + 2047) / 2048;
+    const uint64_t nmat = nseg * nblk;
+    const bool segsort = !ctx->msm_legacy_sort && m <= (1u << 23) && nseg * 4 <= 64 * 1024 && nmat < (1ull << 31);
+    if (segsort) {
+        if ((rc = ensure(ctx, ctx->blk_hist, nmat * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->blk_base, (nmat + 1) * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->blocksums, (size_t)((nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks) * 4))) return rc;
+        blocksums = (uint32_t*)ctx->blocksums.p;
+        StageTimer st(ctx, "msm_sort");
+        launch_msm_segsort(d_scalars, (uint64_t)m, c, W, top_v, (uint32_t)hb, (uint32_t*)ctx->blk_hist.p,
+                           (uint32_t*)ctx->blk_base.p, blocksums, keys, counts, offsets, sorted, s);
+    } else {
+        {
+            StageTimer st(ctx, "msm_digits");
+            HIPCHK(hipMemsetAsync(counts, 0, nb * 4, s));
+            launch_msm_digits(d_scalars, (uint64_t)m, c, W, top_v, keys, counts, s);
+        }
+        {
+            StageTimer st(ctx, "msm_scan");
+            launch_scan(counts, nb, blocksums, offsets, cursor, s);
+        }
+        {
+            StageTimer st(ctx, "msm_scatter");
+            launch_msm_scatter(keys, (uint64_t)m, total, cursor, sorted, s);
+        }
     }
     {
         StageTimer st(ctx, "msm_order");
         launch_bucket_order(counts, (uint32_t)nb, (uint32_t*)ctx->ohist.p, (uint32_t*)ctx->order.p, s);
-    }
-    {
-        StageTimer st(ctx, "msm_scatter");
-        launch_msm_scatter(keys, (uint64_t)m, total, cursor, sorted, s);
     }
     {
         StageTimer st(ctx, "msm_accum");
@@ -537,6 +557,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         int c = atoi(e);
         if (c >= 4 && c <= 20) ctx->msm_c_override = c;
     }
+    if (const char* e = getenv("TYPLONK_MSM_SORT")) ctx->msm_legacy_sort = (strcmp(e, "atomic") == 0);
     *out = ctx;
     return TYPLONK_OK;
 }
@@ -549,7 +570,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
     for (DevBuf* b : {&ctx->scal, &ctx->keys, &ctx->sorted, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->blocksums,
-                      &ctx->buckets, &ctx->part_a, &ctx->part_b, &ctx->order, &ctx->ohist, &ctx->ntt_scratch, &ctx->ntt_io})
+                      &ctx->buckets, &ctx->part_a, &ctx->part_b, &ctx->order, &ctx->ohist, &ctx->blk_hist, &ctx->blk_base, &ctx->ntt_scratch, &ctx->ntt_io})
         release(*b);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -386,7 +386,7 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
 
 void launch_bucket_order(const uint32_t* counts, uint32_t n, uint32_t* hist512, uint32_t* order, hipStream_t s) {
     // hist512: 512 u32 of scratch (histogram + running bases)
-    hipMemsetAsync(hist512, 0, 512 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(hist512, 0, 512 * sizeof(uint32_t), s);
     const uint32_t nblk = (n + 255) / 256;
     hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist512);
     hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist512, hist512 + 256);
