@@ -25,7 +25,7 @@ struct DevBuf {
 };
 
 struct SrsEntry {
-    uint32_t* d_points = nullptr;  // len * 24 u32, identity encoded (0,0)
+    uint32_t* d_points = nullptr;  // len * PT_WORDS u32 (96 B payload on a 128-B stride), identity = (0,0)
     size_t len = 0;
 };
 
@@ -594,9 +594,9 @@ int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, s
     HIPCHK(hipSetDevice(ctx->device));
     SrsEntry e;
     e.len = len;
-    HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * 96));
+    HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * PT_WORDS * 4));
     if (len) {
-        HIPCHK(hipMemcpyAsync(e.d_points, xy, len * 96, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(e.d_points, PT_WORDS * 4, xy, 96, 96, len, hipMemcpyHostToDevice, ctx->stream));
         uint8_t* d_inf = nullptr;
         if (inf) {
             HIPCHK(hipMalloc((void**)&d_inf, len));
@@ -636,7 +636,7 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
     HIPCHK(hipSetDevice(ctx->device));
     SrsEntry e;
     e.len = len;
-    HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * 96));
+    HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * PT_WORDS * 4));
     if (len) {
         Fr s;
         memcpy(s.v, secret, sizeof(s.v));
@@ -656,7 +656,8 @@ int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
     if (offset > it->second.len || count > it->second.len - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside SRS");
     if (!count) return TYPLONK_OK;
-    HIPCHK(hipMemcpyAsync(xy, it->second.d_points + offset * 24, count * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpy2DAsync(xy, 96, it->second.d_points + offset * PT_WORDS, PT_WORDS * 4, 96, count, hipMemcpyDeviceToHost,
+                            ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < count; ++i) {  // internal packed form -> arkworks; (0,0) -> ark-ec (0, 1, inf)
         G1Affine a;

@@ -10,6 +10,10 @@ namespace ty {
 
 constexpr int SCAN_PER_BLOCK = 2048;  // 256 threads x 8
 constexpr int MSM_SEG = 8;            // buckets per reduce thread
+// Resident SRS points are 96 B of payload (x || y packed) on a 128-B stride: every gather of the
+// accumulate kernel then touches exactly one 128-B line instead of 1.75 on average (PMC FETCH_SIZE
+// of msm_accum_kernel: 3.9 GB -> see profiles/).
+constexpr int PT_WORDS = 32;
 
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s);
 

@@ -11,7 +11,7 @@ struct PackedPoint {
     uint4 w[6];
 };
 __device__ __forceinline__ PackedPoint ld_packed(const uint32_t* points, uint32_t idx) {
-    const uint4* q = reinterpret_cast<const uint4*>(points + (uint64_t)idx * 24);
+    const uint4* q = reinterpret_cast<const uint4*>(points + (uint64_t)idx * PT_WORDS);
     PackedPoint p;
 #pragma unroll
     for (int i = 0; i < 6; ++i) p.w[i] = q[i];

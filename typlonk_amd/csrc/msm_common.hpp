@@ -17,6 +17,7 @@
 // the non-deterministic order inside a bucket (atomics in step 3) cannot change the output.
 #pragma once
 #include "g1.hpp"
+#include "launch.hpp"
 
 namespace ty {
 
@@ -40,7 +41,7 @@ __device__ __forceinline__ void st_fq(uint32_t* p, const Fq30& r) {
     q[2] = make_uint4(w[8], w[9], w[10], w[11]);
 }
 __device__ __forceinline__ G1Affine ld_affine(const uint32_t* pts, uint64_t idx) {
-    const uint32_t* p = pts + idx * 24;
+    const uint32_t* p = pts + idx * PT_WORDS;
     G1Affine r;
     r.x = ld_fq(p);
     r.y = ld_fq(p + 12);

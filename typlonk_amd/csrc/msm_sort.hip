@@ -10,7 +10,7 @@ namespace ty {
 __global__ void msm_convert_points_kernel(uint32_t* pts, const uint8_t* inf, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t* p = pts + i * 24;
+    uint32_t* p = pts + i * PT_WORDS;
     if (inf && inf[i]) {
         for (int w = 0; w < 24; ++w) p[w] = 0;
         return;

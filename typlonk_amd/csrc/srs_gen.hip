@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void srs_generate_kernel(SrsGenArgs a) {
         }
     }
     const G1Affine r = g1_to_affine(acc);
-    uint32_t* p = a.pts + i * 24;
+    uint32_t* p = a.pts + i * PT_WORDS;
     st_fq(p, r.x);
     st_fq(p + 12, r.y);
 }
