@@ -1,0 +1,301 @@
+// C++ host-side mirror of the reference's interface for the MSM + NTT path, written above the C ABI
+// (include/typlonk.h).  The reference is Rust; this image has no Rust toolchain, so the host side is
+// C++ with the reference's names, argument meaning and error behaviour (panics -> exceptions):
+//
+//   kzg::Srs                    /root/reference/kzg/src/srs.rs:8-51      (from_secret, g1_ref)
+//   kzg::KzgScheme              /root/reference/kzg/src/lib.rs:15-86     (commit, open, identity)
+//   kzg::KzgCommitment/Opening  /root/reference/kzg/src/lib.rs:16-31, 110-158
+//   poly::DensePolynomial       ark-poly 0.3.0 as used by the reference  (from_coefficients_vec trims
+//                               trailing zeros; degree(); evaluate = Horner; division by X - z)
+//   poly::Radix2EvaluationDomain / Evaluations::interpolate / evaluate_over_domain
+//                               call sites /root/reference/plonk/src/proof.rs:50,106,115 ;
+//                               plonk/src/builder.rs:70,85 ; plonk/src/utils.rs:150-159 (l0_poly)
+//
+// Every group / transform operation goes to the GPU through the C ABI; the O(n) glue the reference
+// does on the CPU (Horner, synthetic division) is done on the CPU here too, with the library's own
+// Fr arithmetic (csrc/ff.hpp).  Nothing here touches the oracle.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/typlonk.h"
+#include "../csrc/ff.hpp"
+
+namespace typlonk {
+
+inline void check(int rc, typlonk_ctx* ctx = nullptr) {
+    if (rc < 0)
+        throw std::runtime_error(std::string(typlonk_strerror(rc)) + (ctx ? std::string(": ") + typlonk_last_error(ctx) : ""));
+}
+
+// ---- Fr ------------------------------------------------------------------------------------------
+// Same bytes as ark_bls12_381::Fr: 4 x u64 little-endian Montgomery limbs.
+struct Fr {
+    ty::Fr v;
+    Fr() : v(ty::Fr::zero()) {}
+    explicit Fr(const ty::Fr& x) : v(x) {}
+    Fr(int64_t x) {  // Fr::from(i32/i64): negative values wrap to r - |x|
+        ty::Fr c = ty::Fr::zero();
+        const uint64_t a = x < 0 ? (uint64_t)(-x) : (uint64_t)x;
+        c.v[0] = (uint32_t)a;
+        c.v[1] = (uint32_t)(a >> 32);
+        v = ty::fe_to_mont(c);
+        if (x < 0) v = ty::fe_neg(v);
+    }
+    static Fr zero() { return Fr(); }
+    static Fr one() { return Fr(ty::Fr::one()); }
+    bool is_zero() const { return v.is_zero(); }
+    Fr operator+(const Fr& o) const { return Fr(ty::fe_add(v, o.v)); }
+    Fr operator-(const Fr& o) const { return Fr(ty::fe_sub(v, o.v)); }
+    Fr operator*(const Fr& o) const { return Fr(ty::fe_mul(v, o.v)); }
+    Fr operator-() const { return Fr(ty::fe_neg(v)); }
+    Fr& operator+=(const Fr& o) { return *this = *this + o; }
+    Fr& operator-=(const Fr& o) { return *this = *this - o; }
+    Fr& operator*=(const Fr& o) { return *this = *this * o; }
+    bool operator==(const Fr& o) const { return v == o.v; }
+    bool operator!=(const Fr& o) const { return !(v == o.v); }
+    Fr inverse() const { return Fr(ty::fe_inv(v)); }
+    Fr pow(uint64_t e) const {
+        uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
+        return Fr(ty::fe_pow(v, w, 2));
+    }
+    const uint64_t* limbs() const { return reinterpret_cast<const uint64_t*>(v.v); }
+    uint64_t* limbs() { return reinterpret_cast<uint64_t*>(v.v); }
+};
+static_assert(sizeof(Fr) == 32, "Fr must be 4 x u64");
+
+// ---- context (one per process / GPU) --------------------------------------------------------------
+class Context {
+   public:
+    explicit Context(int device = 0) { check(typlonk_init(&ctx_, device)); }
+    ~Context() { typlonk_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    typlonk_ctx* raw() const { return ctx_; }
+
+   private:
+    typlonk_ctx* ctx_ = nullptr;
+};
+
+namespace poly {
+
+// ark-poly 0.3.0 DensePolynomial<Fr>
+struct DensePolynomial {
+    std::vector<Fr> coeffs;
+
+    static DensePolynomial from_coefficients_vec(std::vector<Fr> c) {
+        while (!c.empty() && c.back().is_zero()) c.pop_back();  // ark-poly trims trailing zeros
+        DensePolynomial p;
+        p.coeffs = std::move(c);
+        return p;
+    }
+    static DensePolynomial from_coefficients_slice(const std::vector<Fr>& c) { return from_coefficients_vec(c); }
+    bool is_zero() const { return coeffs.empty(); }
+    size_t degree() const { return coeffs.empty() ? 0 : coeffs.size() - 1; }
+    Fr evaluate(const Fr& x) const {  // Horner
+        Fr acc;
+        for (size_t i = coeffs.size(); i-- > 0;) acc = acc * x + coeffs[i];
+        return acc;
+    }
+    // (self - self(z)) / (X - z): the division `&polynomial / &root` of kzg/src/lib.rs:58-61.
+    // Returns the quotient; *y receives self(z).
+    DensePolynomial divide_by_linear(const Fr& z, Fr* y) const {
+        std::vector<Fr> q(coeffs.size() > 0 ? coeffs.size() - 1 : 0);
+        Fr carry;
+        for (size_t i = coeffs.size(); i-- > 1;) {
+            carry = carry * z + coeffs[i];
+            q[i - 1] = carry;
+        }
+        if (!coeffs.empty()) carry = carry * z + coeffs[0];
+        if (y) *y = carry;
+        return from_coefficients_vec(std::move(q));
+    }
+    DensePolynomial operator*(const Fr& k) const {
+        std::vector<Fr> c(coeffs);
+        for (auto& x : c) x *= k;
+        return from_coefficients_vec(std::move(c));
+    }
+};
+
+// ark-poly 0.3.0 Radix2EvaluationDomain<Fr> (what GeneralEvaluationDomain::new returns for BLS12-381 Fr)
+class Radix2EvaluationDomain {
+   public:
+    // GeneralEvaluationDomain::new(num_coeffs): size = next power of two; None (here: exception, the
+    // reference unwrap()s, plonk/src/builder.rs:70) beyond the two-adicity 2^32.
+    Radix2EvaluationDomain(const Context& ctx, uint64_t num_coeffs) : ctx_(&ctx) {
+        log_size_ = 0;
+        while ((1ull << log_size_) < num_coeffs) {
+            if (++log_size_ > 32) check(TYPLONK_ERR_DOMAIN);
+        }
+        size_ = 1ull << log_size_;
+        // TWO_ADIC_ROOT_OF_UNITY = 7^((r-1)/2^32), squared (32 - log_size) times
+        ty::Fr c;
+        const uint32_t root[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u,
+                                  0x22c813b4u, 0xd09b6819u, 0xdfe81f20u, 0x16a2a19eu};
+        for (int i = 0; i < 8; ++i) c.v[i] = root[i];
+        Fr w(ty::fe_to_mont(c));
+        for (uint32_t i = log_size_; i < 32; ++i) w = w * w;
+        group_gen = w;
+        group_gen_inv = w.inverse();
+        size_inv = Fr((int64_t)size_).inverse();
+    }
+    uint64_t size() const { return size_; }
+    uint32_t log_size_of_group() const { return log_size_; }
+    Fr element(uint64_t i) const { return group_gen.pow(i); }
+    Fr evaluate_vanishing_polynomial(const Fr& tau) const { return tau.pow(size_) - Fr::one(); }
+
+    // natural order in / out; input shorter than size() is zero-padded (ark-poly fft semantics)
+    std::vector<Fr> fft(const std::vector<Fr>& coeffs) const { return transform(coeffs, 0, nullptr); }
+    std::vector<Fr> ifft(const std::vector<Fr>& evals) const { return transform(evals, 1, nullptr); }
+    std::vector<Fr> coset_fft(const std::vector<Fr>& coeffs, const Fr& g) const { return transform(coeffs, 0, &g); }
+    std::vector<Fr> coset_ifft(const std::vector<Fr>& evals, const Fr& g) const { return transform(evals, 1, &g); }
+
+    Fr group_gen, group_gen_inv, size_inv;
+
+   private:
+    std::vector<Fr> transform(const std::vector<Fr>& in, int inverse, const Fr* coset) const {
+        if (in.size() > size_) throw std::runtime_error("more coefficients than the domain size");
+        std::vector<Fr> v(in);
+        v.resize(size_);
+        check(typlonk_ntt_fr(ctx_->raw(), v[0].limbs(), log_size_, inverse, coset ? coset->limbs() : nullptr), ctx_->raw());
+        return v;
+    }
+    const Context* ctx_;
+    uint64_t size_;
+    uint32_t log_size_;
+};
+
+// Evaluations::from_vec_and_domain(v, D).interpolate()  /  DensePolynomial::evaluate_over_domain(D)
+inline DensePolynomial interpolate(const std::vector<Fr>& evals, const Radix2EvaluationDomain& d) {
+    return DensePolynomial::from_coefficients_vec(d.ifft(evals));
+}
+inline std::vector<Fr> evaluate_over_domain(const DensePolynomial& p, const Radix2EvaluationDomain& d) {
+    return d.fft(p.coeffs);
+}
+
+}  // namespace poly
+
+namespace kzg {
+
+using Poly = poly::DensePolynomial;
+
+// ark_bls12_381::G1Affine at the C ABI: x || y Montgomery limbs + infinity flag
+struct G1Point {
+    uint64_t xy[12];
+    bool infinity;
+    bool operator==(const G1Point& o) const {
+        if (infinity || o.infinity) return infinity == o.infinity;
+        return std::memcmp(xy, o.xy, sizeof(xy)) == 0;
+    }
+    bool operator!=(const G1Point& o) const { return !(*this == o); }
+};
+
+// kzg/src/srs.rs: g1 = [G, sG, s^2 G, ...] of length gates + 3, resident on the device
+class Srs {
+   public:
+    static Srs from_secret(const Context& ctx, const Fr& s, size_t gates) {
+        Srs r(ctx);
+        r.len_ = gates + 3;
+        check(typlonk_srs_generate(ctx.raw(), s.limbs(), 0, r.len_, &r.id_), ctx.raw());
+        return r;
+    }
+    static Srs from_points(const Context& ctx, const std::vector<G1Point>& pts) {
+        Srs r(ctx);
+        r.len_ = pts.size();
+        std::vector<uint64_t> xy(pts.size() * 12);
+        std::vector<uint8_t> inf(pts.size());
+        for (size_t i = 0; i < pts.size(); ++i) {
+            std::memcpy(&xy[i * 12], pts[i].xy, 96);
+            inf[i] = pts[i].infinity;
+        }
+        check(typlonk_srs_load(ctx.raw(), xy.data(), inf.data(), pts.size(), &r.id_), ctx.raw());
+        return r;
+    }
+    Srs(Srs&& o) noexcept : ctx_(o.ctx_), id_(o.id_), len_(o.len_) { o.id_ = 0; }
+    Srs(const Srs&) = delete;
+    ~Srs() {
+        if (id_) typlonk_srs_free(ctx_->raw(), id_);
+    }
+    size_t len() const { return len_; }
+    std::vector<G1Point> g1_ref() const {  // downloads the points (the reference returns &Vec<G1Point>)
+        std::vector<uint64_t> xy(len_ * 12);
+        std::vector<uint8_t> inf(len_);
+        check(typlonk_srs_download(ctx_->raw(), id_, 0, len_, xy.data(), inf.data()), ctx_->raw());
+        std::vector<G1Point> out(len_);
+        for (size_t i = 0; i < len_; ++i) {
+            std::memcpy(out[i].xy, &xy[i * 12], 96);
+            out[i].infinity = inf[i] != 0;
+        }
+        return out;
+    }
+    uint32_t id() const { return id_; }
+    const Context& ctx() const { return *ctx_; }
+
+   private:
+    explicit Srs(const Context& c) : ctx_(&c) {}
+    const Context* ctx_;
+    uint32_t id_ = 0;
+    size_t len_ = 0;
+};
+
+struct KzgCommitment {
+    G1Point p;
+    const G1Point& inner() const { return p; }
+    bool operator==(const KzgCommitment& o) const { return p == o.p; }
+};
+struct KzgOpening {
+    G1Point p;
+    Fr y;
+    Fr eval() const { return y; }
+};
+
+class KzgScheme {
+   public:
+    explicit KzgScheme(const Srs& srs) : srs_(srs) {}
+    KzgCommitment commit(const Poly& polynomial) const { return KzgCommitment{evaluate_in_s(polynomial)}; }
+    // kzg/src/lib.rs:55-64
+    KzgOpening open(const Poly& polynomial, const Fr& z) const {
+        if (polynomial.coeffs.empty()) throw std::runtime_error("at least 1");  // `.expect("at least 1")`
+        Fr y;
+        const Poly q = polynomial.divide_by_linear(z, &y);
+        return KzgOpening{evaluate_in_s(q), y};
+    }
+    KzgCommitment identity() const { return commit(Poly::from_coefficients_vec({Fr(1)})); }
+
+   private:
+    // kzg/src/lib.rs:41-54: assert!(srs.len() > degree) then sum coeff_i * srs_i -> the MSM
+    G1Point evaluate_in_s(const Poly& polynomial) const {
+        if (!(srs_.len() > polynomial.degree())) throw std::runtime_error("assertion failed: srs.len() > polynomial.degree()");
+        G1Point out;
+        uint8_t inf = 0;
+        const uint64_t* sc = polynomial.coeffs.empty() ? nullptr : polynomial.coeffs[0].limbs();
+        check(typlonk_msm_g1(srs_.ctx().raw(), srs_.id(), sc, polynomial.coeffs.size(), out.xy, &inf), srs_.ctx().raw());
+        out.infinity = inf != 0;
+        return out;
+    }
+    const Srs& srs_;
+};
+
+// group helpers used by the tests (KzgCommitment: Add / Mul<Fr>, kzg/src/lib.rs:110-158)
+inline G1Point g1_add(const G1Point& a, const G1Point& b) {
+    uint64_t xy[24];
+    uint8_t inf[2] = {(uint8_t)a.infinity, (uint8_t)b.infinity};
+    std::memcpy(xy, a.xy, 96);
+    std::memcpy(xy + 12, b.xy, 96);
+    G1Point out;
+    uint8_t oi = 0;
+    check(typlonk_g1_sum_host(xy, inf, 2, out.xy, &oi));
+    out.infinity = oi != 0;
+    return out;
+}
+inline G1Point g1_mul(const Context& ctx, const G1Point& p, const Fr& k) {
+    Srs one = Srs::from_points(ctx, {p});
+    return KzgScheme(one).commit(Poly::from_coefficients_vec({k})).p;
+}
+inline G1Point g1_neg(const Context& ctx, const G1Point& p) { return g1_mul(ctx, p, -Fr::one()); }
+
+}  // namespace kzg
+}  // namespace typlonk
