@@ -76,6 +76,13 @@ int typlonk_msm_g1_dev(typlonk_ctx* ctx, uint32_t srs_id, const typlonk_buf* sca
 int typlonk_msm_g1_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scalars, size_t m,
                           uint64_t out_xy[12], uint8_t* out_inf);
 
+/* `count` independent MSMs over the same SRS (prove() issues them in groups: the three wire
+ * commitments plonk/src/proof.rs:107-110, the openings :147-175, the quotient slices :181).  Two are
+ * kept in flight on alternating workspaces/streams so one MSM's reduction tail overlaps the next one's
+ * accumulation.  d_scalars[k]: device pointer to m[k] Fr elements; out_xy: count*12 limbs; out_inf: count. */
+int typlonk_msm_g1_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m,
+                                size_t count, uint64_t* out_xy, uint8_t* out_inf);
+
 /* ---- NTT over Fr: radix-2 domain of size 2^log_n with arkworks' generator -------------------------
  * omega = TWO_ADIC_ROOT_OF_UNITY^(2^(32-log_n)).  Natural order in, natural order out, in place.
  *   inverse = 0: data[k] <- sum_i data[i] * (g*omega^k)^i                (fft / coset_fft)

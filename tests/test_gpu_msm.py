@@ -201,3 +201,31 @@ def test_golden_msm_fixtures(ctx):
         out, inf = ctx.msm(sid, fr_pack(sc) if sc else np.zeros((0, 4), dtype=np.uint64), len(sc))
         assert g1_unpack_one(out, inf) == hex_pt(case["expected"])
         ctx.srs_free(sid)
+
+
+def test_batch_matches_individual_msms(ctx):
+    """typlonk_msm_g1_batch_devptr (two MSMs in flight) == the same MSMs issued one by one,
+    for the mixed lengths prove() uses (n, n-1, n-3) plus the empty polynomial."""
+    n = 1 << 12
+    s_limbs = np.array(O.fr_to_mont_limbs(2), dtype=np.uint64)
+    sid = ctx.srs_generate(s_limbs, n + 3)
+    rng = np.random.default_rng(77)
+    bufs, ms = [], [n, n - 1, 0, n - 3, n, 17, n - 1]
+    for m in ms:
+        sc = rng.integers(0, 1 << 63, size=(max(m, 1), 4), dtype=np.uint64)
+        sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+        b = ctx.alloc(max(m, 1))
+        b.upload(sc)
+        bufs.append((b, sc))
+    single = [ctx.msm_devptr(sid, b.devptr, m) for (b, _), m in zip(bufs, ms)]
+    batch = ctx.msm_batch_devptr(sid, [b.devptr for b, _ in bufs], ms)
+    for (sx, si), (bx, bi) in zip(single, batch):
+        assert (sx == bx).all() and si == bi
+    assert batch[2][1] == 1
+    # and against the oracle identity for one of them
+    from oracle import coracle as CO
+    exp, einf = CO.g1_mul_generator(CO.poly_eval(bufs[1][1][: n - 1], s_limbs))
+    assert (batch[1][0] == exp).all() and batch[1][1] == einf
+    for b, _ in bufs:
+        b.free()
+    ctx.srs_free(sid)

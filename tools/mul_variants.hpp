@@ -44,4 +44,27 @@ __device__ __forceinline__ Fe<P> fe_mul_ps(const Fe<P>& a, const Fe<P>& b) {
     return o;
 }
 
+// V4: 13x30 product phase with two interleaved accumulator chains (even / odd columns carry-free,
+// merged afterwards) to expose ILP to a single wave
+__device__ __forceinline__ Fq30 fq30_mul_ilp(const Fq30& a, const Fq30& b) {
+    uint64_t col[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = (k > 12 ? k - 12 : 0); i <= (k < 12 ? k : 12); ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        col[k] = acc;
+    }
+    uint32_t T[26];
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        c += col[k];      // < 2^64: col < 13*2^60, carry < 2^35
+        T[k] = (uint32_t)c & FQ30_MASK;
+        c >>= 30;
+    }
+    T[25] = (uint32_t)c;
+    return fq30_redc(T);
+}
+
 }  // namespace ty

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void fq_variant_kernel(uint32_t* out, int iter
         a.v[11] &= 0x0fffffffu; b.v[11] &= 0x0fffffffu;
         for (int i = 0; i < iters; ++i) { a = fe_mul_ps(a, b); b = fe_mul_ps(b, a); }
         for (int i = 0; i < 12; ++i) s += a.v[i] ^ b.v[i];
+    } else if (V == 4) {
+        Fq30 a, b;
+        for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & FQ30_MASK; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & FQ30_MASK; }
+        for (int i = 0; i < iters; ++i) { a = fq30_mul_ilp(a, b); b = fq30_mul_ilp(b, a); }
+        for (int i = 0; i < 13; ++i) s += a.v[i] ^ b.v[i];
     } else {
         Fq30 a, b;
         for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & FQ30_MASK; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & FQ30_MASK; }
@@ -132,14 +137,15 @@ int main() {
         const int it = 256;
         double t = time_ms([&] { hipLaunchKernelGGL(fmul_kernel<Fq>, dim3(blocks), dim3(threads), 0, 0, out, it); });
         printf("Fq mul (12x32 CIOS)      %8.3f ms  %8.2f G mul/s\n", t, (double)blocks * threads * it * 2 / t * 1e-6);
-        for (int occ = 8; occ >= 2; occ /= 2) {
+        for (int occ = 8; occ >= 1; occ /= 2) {
             const int nb = prop.multiProcessorCount * occ;
             double t1 = time_ms([&] { hipLaunchKernelGGL(fmul_kernel<Fq>, dim3(nb), dim3(threads), 0, 0, out, it); });
             double t2 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<2>, dim3(nb), dim3(threads), 0, 0, out, it); });
             double t3 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<3>, dim3(nb), dim3(threads), 0, 0, out, it); });
-            printf("Fq mul @%d blocks/CU: CIOS %.2f | product-scan asm %.2f | 13x30 unsaturated %.2f  G mul/s\n", occ,
+            double t4 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<4>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            printf("Fq mul @%d blocks/CU: CIOS %.2f | product-scan asm %.2f | 13x30 %.2f | 13x30 indep-columns %.2f  G mul/s\n", occ,
                    (double)nb * threads * it * 2 / t1 * 1e-6, (double)nb * threads * it * 2 / t2 * 1e-6,
-                   (double)nb * threads * it * 2 / t3 * 1e-6);
+                   (double)nb * threads * it * 2 / t3 * 1e-6, (double)nb * threads * it * 2 / t4 * 1e-6);
         }
         t = time_ms([&] { hipLaunchKernelGGL(fmul_kernel<Fr>, dim3(blocks), dim3(threads), 0, 0, out, it); });
         printf("Fr mul (8x32 CIOS)       %8.3f ms  %8.2f G mul/s\n", t, (double)blocks * threads * it * 2 / t * 1e-6);

@@ -18,7 +18,7 @@ ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RA
 SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
-    "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
+    "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
     "typlonk_ntt_fr_devptr", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
@@ -62,6 +62,7 @@ def load_library() -> C.CDLL:
     lib.typlonk_msm_g1.argtypes = [vp, C.c_uint32, u64p, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_dev.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_devptr.argtypes = [vp, C.c_uint32, vp, C.c_size_t, u64p, u8p]
+    lib.typlonk_msm_g1_batch_devptr.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, u64p, u8p]
     lib.typlonk_ntt_fr.argtypes = [vp, u64p, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_devptr.argtypes = [vp, vp, C.c_uint32, C.c_int, u64p]
@@ -234,6 +235,16 @@ class Context:
         oinf = np.zeros(1, dtype=np.uint8)
         self._chk(self.lib.typlonk_msm_g1_devptr(self.h, sid, devptr, m, _u64p(out), _u8p(oinf)))
         return out, int(oinf[0])
+
+    def msm_batch_devptr(self, sid: int, devptrs, ms):
+        """independent MSMs over one SRS, pipelined two at a time -> list of (xy[12], inf)"""
+        n = len(devptrs)
+        ptrs = (C.c_void_p * n)(*devptrs)
+        lens = (C.c_size_t * n)(*ms)
+        out = np.zeros((n, 12), dtype=np.uint64)
+        oinf = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.typlonk_msm_g1_batch_devptr(self.h, sid, ptrs, lens, n, _u64p(out), _u8p(oinf)))
+        return [(out[i], int(oinf[i])) for i in range(n)]
 
     def msm_plan(self, m: int):
         c, w, ops = C.c_uint32(), C.c_uint32(), C.c_uint64()

@@ -39,6 +39,21 @@ struct ProfStage {
     hipEvent_t a, b;
 };
 
+// Everything one in-flight MSM needs: grow-only device workspaces, the stream it was enqueued on and
+// the pinned landing zone of its window sums.  A context owns two, so that a batch of independent
+// MSMs (prove() issues them in groups: 3 wire commitments, 5-6 openings, 3 quotient slices --
+// plonk/src/proof.rs:107-110, 147-175, 181) can overlap one MSM's host-side finish (window combine, affine
+// normalisation) and kernel tail with the next one's sort + accumulate.
+struct MsmWs {
+    DevBuf keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist, blk_hist, blk_base;
+    hipStream_t stream = nullptr;
+    uint32_t* host_wins = nullptr;  // pinned, 64 windows x 48 words
+    bool pending = false;
+    uint32_t W = 0, c = 0;
+    uint64_t* out_xy = nullptr;
+    uint8_t* out_inf = nullptr;
+};
+
 }  // namespace
 
 struct typlonk_buf {
@@ -53,8 +68,11 @@ struct typlonk_ctx {
     std::string err;
     std::map<uint32_t, SrsEntry> srs;
     uint32_t next_srs = 1;
-    // MSM workspaces (grow-only)
-    DevBuf scal, keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist, blk_hist, blk_base;
+    // MSM
+    DevBuf scal;
+    MsmWs ws[2];
+    hipStream_t stream2 = nullptr;  // second lane of typlonk_msm_g1_batch*
+    hipEvent_t batch_evt = nullptr;
     // NTT
     DevBuf ntt_scratch, ntt_io;
     std::map<std::string, Table> tables;
@@ -104,16 +122,17 @@ struct StageTimer {
     bool on;
     hipEvent_t a = nullptr, b = nullptr;
     const char* name;
-    StageTimer(typlonk_ctx* c, const char* n) : ctx(c), on(c->profiling), name(n) {
+    hipStream_t st;
+    StageTimer(typlonk_ctx* c, const char* n, hipStream_t s = nullptr) : ctx(c), on(c->profiling), name(n), st(s ? s : c->stream) {
         if (on) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, ctx->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~StageTimer() {
         if (on) {
-            (void)hipEventRecord(b, ctx->stream);
+            (void)hipEventRecord(b, st);
             ctx->prof.push_back({name, a, b});
         }
     }
@@ -390,20 +409,12 @@ G1Xyzz unpack_xyzz(const uint32_t* p) {
     return r;
 }
 
-int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12],
-            uint8_t* out_inf) {
-    if (!out_xy || !out_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
-    auto it = ctx->srs.find(srs_id);
-    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
-    const SrsEntry& srs = it->second;
-    if (m > srs.len) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
-    prof_begin(ctx);
-    if (m == 0) {
-        write_affine_out(G1Affine::inf(), out_xy, out_inf);
-        prof_collect(ctx);
-        return TYPLONK_OK;
-    }
-    if (!d_scalars) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null scalars");
+// Launch every kernel of one m-term MSM (m > 0, validated by the caller) on `stream` using workspace
+// `ws`, ending with the asynchronous copy of the W window sums into ws.host_wins.
+int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry& srs, const Fr* d_scalars, size_t m,
+                uint64_t* out_xy, uint8_t* out_inf) {
+    ws.stream = stream;
+    if (!ws.host_wins) HIPCHK(hipHostMalloc((void**)&ws.host_wins, 64 * 192));
     uint32_t c, W;
     msm_shape(ctx, m, &c, &W);
     const uint32_t B = 1u << (c - 1);
@@ -419,28 +430,28 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     const uint32_t scan_blocks = (uint32_t)((nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
 
     int rc;
-    if ((rc = ensure(ctx, ctx->keys, total * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->sorted, total * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->counts, nb * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->offsets, (nb + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cursor, nb * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->blocksums, (size_t)scan_blocks * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->buckets, nb * 192))) return rc;
-    if ((rc = ensure(ctx, ctx->order, nb * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->ohist, 512 * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->part_a, (size_t)nodes * 192))) return rc;
-    if ((rc = ensure(ctx, ctx->part_b, (size_t)nodes * 192))) return rc;
+    if ((rc = ensure(ctx, ws.keys, total * 4))) return rc;
+    if ((rc = ensure(ctx, ws.sorted, total * 4))) return rc;
+    if ((rc = ensure(ctx, ws.counts, nb * 4))) return rc;
+    if ((rc = ensure(ctx, ws.offsets, (nb + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ws.cursor, nb * 4))) return rc;
+    if ((rc = ensure(ctx, ws.blocksums, (size_t)scan_blocks * 4))) return rc;
+    if ((rc = ensure(ctx, ws.buckets, nb * 192))) return rc;
+    if ((rc = ensure(ctx, ws.order, nb * 4))) return rc;
+    if ((rc = ensure(ctx, ws.ohist, 512 * 4))) return rc;
+    if ((rc = ensure(ctx, ws.part_a, (size_t)nodes * 192))) return rc;
+    if ((rc = ensure(ctx, ws.part_b, (size_t)nodes * 192))) return rc;
 
-    uint32_t* keys = (uint32_t*)ctx->keys.p;
-    uint32_t* sorted = (uint32_t*)ctx->sorted.p;
-    uint32_t* counts = (uint32_t*)ctx->counts.p;
-    uint32_t* offsets = (uint32_t*)ctx->offsets.p;
-    uint32_t* cursor = (uint32_t*)ctx->cursor.p;
-    uint32_t* blocksums = (uint32_t*)ctx->blocksums.p;
-    uint32_t* buckets = (uint32_t*)ctx->buckets.p;
-    uint32_t* pa = (uint32_t*)ctx->part_a.p;
-    uint32_t* pb = (uint32_t*)ctx->part_b.p;
-    hipStream_t s = ctx->stream;
+    uint32_t* keys = (uint32_t*)ws.keys.p;
+    uint32_t* sorted = (uint32_t*)ws.sorted.p;
+    uint32_t* counts = (uint32_t*)ws.counts.p;
+    uint32_t* offsets = (uint32_t*)ws.offsets.p;
+    uint32_t* cursor = (uint32_t*)ws.cursor.p;
+    uint32_t* blocksums = (uint32_t*)ws.blocksums.p;
+    uint32_t* buckets = (uint32_t*)ws.buckets.p;
+    uint32_t* pa = (uint32_t*)ws.part_a.p;
+    uint32_t* pb = (uint32_t*)ws.part_b.p;
+    hipStream_t s = ws.stream;
 
     // segmented sort shape: hb high bucket bits pick the segment, lb <= 8 low bits are sorted in LDS
     uint32_t lgm = 0;
@@ -452,41 +463,41 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     const uint64_t nmat = nseg * nblk;
     const bool segsort = !ctx->msm_legacy_sort && m <= (1u << 23) && nseg * 4 <= 64 * 1024 && nmat < (1ull << 31);
     if (segsort) {
-        if ((rc = ensure(ctx, ctx->blk_hist, nmat * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->blk_base, (nmat + 1) * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->blocksums, (size_t)((nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks) * 4))) return rc;
-        blocksums = (uint32_t*)ctx->blocksums.p;
-        StageTimer st(ctx, "msm_sort");
-        launch_msm_segsort(d_scalars, (uint64_t)m, c, W, top_v, (uint32_t)hb, (uint32_t*)ctx->blk_hist.p,
-                           (uint32_t*)ctx->blk_base.p, blocksums, keys, counts, offsets, sorted, s);
+        if ((rc = ensure(ctx, ws.blk_hist, nmat * 4))) return rc;
+        if ((rc = ensure(ctx, ws.blk_base, (nmat + 1) * 4))) return rc;
+        if ((rc = ensure(ctx, ws.blocksums, (size_t)((nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks) * 4))) return rc;
+        blocksums = (uint32_t*)ws.blocksums.p;
+        StageTimer st(ctx, "msm_sort", s);
+        launch_msm_segsort(d_scalars, (uint64_t)m, c, W, top_v, (uint32_t)hb, (uint32_t*)ws.blk_hist.p,
+                           (uint32_t*)ws.blk_base.p, blocksums, keys, counts, offsets, sorted, s);
     } else {
         {
-            StageTimer st(ctx, "msm_digits");
+            StageTimer st(ctx, "msm_digits", s);
             HIPCHK(hipMemsetAsync(counts, 0, nb * 4, s));
             launch_msm_digits(d_scalars, (uint64_t)m, c, W, top_v, keys, counts, s);
         }
         {
-            StageTimer st(ctx, "msm_scan");
+            StageTimer st(ctx, "msm_scan", s);
             launch_scan(counts, nb, blocksums, offsets, cursor, s);
         }
         {
-            StageTimer st(ctx, "msm_scatter");
+            StageTimer st(ctx, "msm_scatter", s);
             launch_msm_scatter(keys, (uint64_t)m, total, cursor, sorted, s);
         }
     }
     {
-        StageTimer st(ctx, "msm_order");
-        launch_bucket_order(counts, (uint32_t)nb, (uint32_t*)ctx->ohist.p, (uint32_t*)ctx->order.p, s);
+        StageTimer st(ctx, "msm_order", s);
+        launch_bucket_order(counts, (uint32_t)nb, (uint32_t*)ws.ohist.p, (uint32_t*)ws.order.p, s);
     }
     {
-        StageTimer st(ctx, "msm_accum");
-        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ctx->order.p, (uint32_t)nb, buckets, s);
+        StageTimer st(ctx, "msm_accum", s);
+        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ws.order.p, (uint32_t)nb, buckets, s);
     }
     uint32_t* cur = pa;
     uint32_t* other = pb;
     uint32_t n_in;
     {
-        StageTimer st(ctx, "msm_reduce");
+        StageTimer st(ctx, "msm_reduce", s);
         const uint32_t group = std::min<uint32_t>(64, npw);
         launch_msm_reduce(buckets, B, L, nodes, group, c, W, top_v, cur, s);
         n_in = npw / group;
@@ -499,21 +510,93 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
         }
     }
     HIPCHK(hipGetLastError());
-    std::vector<uint32_t> wins_raw((size_t)W * 48);
-    HIPCHK(hipMemcpyAsync(wins_raw.data(), cur, (size_t)W * 192, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    std::vector<G1Xyzz> wins(W);
-    for (uint32_t j = 0; j < W; ++j) wins[j] = unpack_xyzz(wins_raw.data() + (size_t)j * 48);
-    // host: sum_j 2^(c*j) * wins[j]  (Horner from the top window), then canonical affine
+    HIPCHK(hipMemcpyAsync(ws.host_wins, cur, (size_t)W * 192, hipMemcpyDeviceToHost, s));
+    ws.pending = true;
+    ws.W = W;
+    ws.c = c;
+    ws.out_xy = out_xy;
+    ws.out_inf = out_inf;
+    return TYPLONK_OK;
+}
+
+// Wait for an enqueued MSM and finish it on the host: sum_j 2^(c*j) * window_j (Horner from the top
+// window), then the canonical affine form.
+int msm_finish(typlonk_ctx* ctx, MsmWs& ws) {
+    if (!ws.pending) return TYPLONK_OK;
+    ws.pending = false;
+    HIPCHK(hipStreamSynchronize(ws.stream));
     G1Xyzz acc = G1Xyzz::inf();
-    for (int j = (int)W - 1; j >= 0; --j) {
+    for (int j = (int)ws.W - 1; j >= 0; --j) {
         if (!acc.is_inf())
-            for (uint32_t d = 0; d < c; ++d) acc = g1_dbl(acc);
-        acc = g1_add(acc, wins[j]);
+            for (uint32_t d = 0; d < ws.c; ++d) acc = g1_dbl(acc);
+        acc = g1_add(acc, unpack_xyzz(ws.host_wins + (size_t)j * 48));
     }
-    write_affine_out(g1_to_affine(acc), out_xy, out_inf);
+    write_affine_out(g1_to_affine(acc), ws.out_xy, ws.out_inf);
+    return TYPLONK_OK;
+}
+
+int msm_validate(typlonk_ctx* ctx, uint32_t srs_id, size_t m, const SrsEntry** srs) {
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    if (m > it->second.len) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
+    *srs = &it->second;
+    return TYPLONK_OK;
+}
+
+int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12],
+            uint8_t* out_inf) {
+    if (!out_xy || !out_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
+    const SrsEntry* srs = nullptr;
+    int rc = msm_validate(ctx, srs_id, m, &srs);
+    if (rc) return rc;
+    prof_begin(ctx);
+    if (m == 0) {
+        write_affine_out(G1Affine::inf(), out_xy, out_inf);
+        prof_collect(ctx);
+        return TYPLONK_OK;
+    }
+    if (!d_scalars) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null scalars");
+    if ((rc = msm_enqueue(ctx, ctx->ws[0], ctx->stream, *srs, d_scalars, m, out_xy, out_inf))) return rc;
+    if ((rc = msm_finish(ctx, ctx->ws[0]))) return rc;
     prof_collect(ctx);
     return TYPLONK_OK;
+}
+
+// count independent MSMs over the same SRS, two in flight at a time (alternating workspaces/streams)
+int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m, size_t count,
+              uint64_t* out_xy, uint8_t* out_inf) {
+    if (!out_xy || !out_inf || !m || (!d_scalars && count)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    const SrsEntry* srs = nullptr;
+    for (size_t k = 0; k < count; ++k) {
+        int rc = msm_validate(ctx, srs_id, m[k], &srs);
+        if (rc) return rc;
+        if (m[k] && !d_scalars[k]) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null scalars");
+    }
+    if (!count) return TYPLONK_OK;
+    prof_begin(ctx);
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;  // stage events are per-call; a batch interleaves two calls
+    if (!ctx->stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->batch_evt) HIPCHK(hipEventCreateWithFlags(&ctx->batch_evt, hipEventDisableTiming));
+    // work already queued on the context's stream (e.g. the iNTT that produced the scalars) must be
+    // visible to the second lane
+    HIPCHK(hipEventRecord(ctx->batch_evt, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->batch_evt, 0));
+    int rc = TYPLONK_OK;
+    for (size_t k = 0; k < count && !rc; ++k) {
+        MsmWs& ws = ctx->ws[k & 1];
+        if ((rc = msm_finish(ctx, ws))) break;
+        if (m[k] == 0) {
+            write_affine_out(G1Affine::inf(), out_xy + 12 * k, out_inf + k);
+            continue;
+        }
+        rc = msm_enqueue(ctx, ws, (k & 1) ? ctx->stream2 : ctx->stream, *srs, (const Fr*)d_scalars[k], m[k],
+                         out_xy + 12 * k, out_inf + k);
+    }
+    int r0 = msm_finish(ctx, ctx->ws[0]);
+    int r1 = msm_finish(ctx, ctx->ws[1]);
+    ctx->profiling = prof;
+    return rc ? rc : (r0 ? r0 : r1);
 }
 
 }  // namespace
@@ -569,9 +652,15 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     prof_begin(ctx);
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
-    for (DevBuf* b : {&ctx->scal, &ctx->keys, &ctx->sorted, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->blocksums,
-                      &ctx->buckets, &ctx->part_a, &ctx->part_b, &ctx->order, &ctx->ohist, &ctx->blk_hist, &ctx->blk_base, &ctx->ntt_scratch, &ctx->ntt_io})
-        release(*b);
+    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io}) release(*b);
+    for (MsmWs& ws : ctx->ws) {
+        for (DevBuf* b : {&ws.keys, &ws.sorted, &ws.counts, &ws.offsets, &ws.cursor, &ws.blocksums, &ws.buckets, &ws.part_a,
+                          &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base})
+            release(*b);
+        if (ws.host_wins) (void)hipHostFree(ws.host_wins);
+    }
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->batch_evt) (void)hipEventDestroy(ctx->batch_evt);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -678,6 +767,13 @@ int typlonk_msm_g1_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scala
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     return msm_run(ctx, srs_id, (const Fr*)d_scalars, m, out_xy, out_inf);
+}
+
+int typlonk_msm_g1_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m,
+                                size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return msm_batch(ctx, srs_id, d_scalars, m, count, out_xy, out_inf);
 }
 
 int typlonk_msm_g1_dev(typlonk_ctx* ctx, uint32_t srs_id, const typlonk_buf* scalars, size_t offset, size_t m,

@@ -56,6 +56,9 @@ class ShardedMsm:
         self.device, self.group = device, group
         self.lo, self.hi = shard_bounds(total_len, world, rank)
         self.sid = None
+        # exercise the all-gather + fold even with one rank (used to validate the RCCL path on a 1-GPU box)
+        import os
+        self.force_collective = os.environ.get("TYPLONK_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
 
     def generate_srs(self, secret_limbs):
         """build only this rank's slice [s^lo G, ..., s^(hi-1) G] in HBM"""
@@ -76,6 +79,6 @@ class ShardedMsm:
         """full m-term MSM result on every rank"""
         lo, hi = local_range(m, self.total_len, self.world, self.rank)
         xy, inf = self.msm_local_devptr(d_scalars_local, hi - lo)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return xy, inf
         return allgather_fold(xy, inf, self.device, self.group)
