@@ -94,6 +94,28 @@ int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32
 int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int inverse,
                           const uint64_t* coset_shift);
 
+/* ---- quotient polynomial (plonk::proof::quotient_polynomial, /root/reference/plonk/src/proof.rs:292-375)
+ * All inputs are device-resident coefficient vectors of n = 2^log_n elements (zero padded), as
+ * produced by typlonk_ntt_fr_dev(inverse): the wire polynomials a, b, c (proof.rs:50), the grand
+ * product Z (:127), the five selector polynomials q_l q_r q_o q_m q_c (builder.rs:84-88), the three
+ * sigma polynomials (proof.rs:334-338) and the public-input polynomial (:105).  Z(wX) is derived
+ * internally.  Scalars are 4-limb Montgomery Fr: challenges alpha, beta, gamma (proof.rs:111, 133) and
+ * the identity-permutation cosets k_0..k_2 (permutation/src/lib.rs:141-154; 2, 3, 4 in the reference).
+ * t_out must hold >= 4n elements; on return its first 3n hold the coefficients of t (degree <= 3n - 4;
+ * the three commitments of SlicedPoly<3> are MSMs of [0,n), [n,2n), [2n,3n)), the rest is zero.
+ * The schoolbook products of the reference are replaced by a 4n coset NTT: identical result
+ * whenever the constraint numerator vanishes on the domain (every valid witness). */
+typedef struct typlonk_quotient_args {
+    const typlonk_buf* wires[3];
+    const typlonk_buf* z;
+    const typlonk_buf* selectors[5];
+    const typlonk_buf* sigma[3];
+    const typlonk_buf* public_inputs;
+    uint64_t alpha[4], beta[4], gamma[4];
+    uint64_t cosets[3][4];
+} typlonk_quotient_args;
+int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out);
+
 /* ---- device-resident Fr vectors (so an iNTT result feeds an MSM without crossing PCIe) ---------- */
 int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out);
 int typlonk_buf_free(typlonk_ctx* ctx, typlonk_buf* buf);

@@ -120,3 +120,28 @@ def test_srs_generators_agree():
     assert (xy == xy2).all() and (inf == inf2).all()
     xy4, _ = CO.srs_pow2_secret(2, 10)
     assert g1_unpack_one(xy4[9], 0) == O.g1_mul(O.G1, pow(4, 9, O.R))
+
+
+def test_quotient_oracle_satisfies_the_reference_asserts():
+    """the identities plonk/src/proof.rs itself asserts: vanishes(line1) :321, vanishes(line4) :361,
+    exact division by the vanishing polynomial, and the slice lengths n, n, n - 3"""
+    from oracle import plonk_oracle as PO
+
+    for log_n in (2, 3, 5):
+        r = PO.prove_round_2_3(log_n, 0x1234567, 0xABCDEF01, 0x55AA55AA77)
+        n = r["n"]
+        assert r["rem"] == []
+        assert PO.divide_by_vanishing_poly(r["line1"], n)[1] == []
+        assert PO.divide_by_vanishing_poly(r["line4"], n)[1] == []
+        assert len(r["t"]) <= 3 * n - 3
+        if log_n >= 3:   # n = 4 has a single gate and a lower-degree quotient
+            assert [len(s) for s in PO.slices(r["t"], n)] == [n, n, n - 3]
+        # Z starts at 1 and the grand product closes (copy constraints hold)
+        assert r["z_evals"][0] == 1
+    # naive_mul / divide_by_vanishing_poly against direct evaluation
+    a, b = O.random_frs(1, 7), O.random_frs(2, 9)
+    x = 987654321
+    assert O.poly_eval(PO.naive_mul(a, b), x) == O.poly_eval(a, x) * O.poly_eval(b, x) % O.R
+    p = O.random_frs(3, 21)
+    q, rem = PO.divide_by_vanishing_poly(p, 8)
+    assert (O.poly_eval(q, x) * (pow(x, 8, O.R) - 1) + O.poly_eval(rem, x)) % O.R == O.poly_eval(p, x)

@@ -19,7 +19,7 @@ SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
-    "typlonk_ntt_fr_devptr", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
@@ -30,6 +30,13 @@ class TyplonkError(RuntimeError):
     def __init__(self, code: int, detail: str = ""):
         self.code = code
         super().__init__(f"typlonk error {code}: {detail}")
+
+
+class QuotientArgs(C.Structure):
+    """typlonk_quotient_args"""
+    _fields_ = [("wires", C.c_void_p * 3), ("z", C.c_void_p), ("selectors", C.c_void_p * 5), ("sigma", C.c_void_p * 3),
+                ("public_inputs", C.c_void_p), ("alpha", C.c_uint64 * 4), ("beta", C.c_uint64 * 4),
+                ("gamma", C.c_uint64 * 4), ("cosets", (C.c_uint64 * 4) * 3)]
 
 
 _lib = None
@@ -66,6 +73,7 @@ def load_library() -> C.CDLL:
     lib.typlonk_ntt_fr.argtypes = [vp, u64p, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_devptr.argtypes = [vp, vp, C.c_uint32, C.c_int, u64p]
+    lib.typlonk_quotient_dev.argtypes = [vp, C.POINTER(QuotientArgs), C.c_uint32, vp]
     lib.typlonk_buf_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.typlonk_buf_free.argtypes = [vp, vp]
     lib.typlonk_buf_upload.argtypes = [vp, vp, C.c_size_t, u64p, C.c_size_t]
@@ -275,6 +283,26 @@ class Context:
     def ntt_devptr(self, devptr: int, log_n: int, inverse: bool = False, coset=None):
         keep, cp = self._coset(coset)
         self._chk(self.lib.typlonk_ntt_fr_devptr(self.h, devptr, log_n, int(inverse), cp))
+
+    def quotient_dev(self, log_n: int, wires, z, selectors, sigma, pi, alpha, beta, gamma, cosets, t_out):
+        """typlonk_quotient_dev: all polynomial arguments are DeviceBuffers (n coefficients), scalars are
+        4-limb Montgomery arrays; t_out is a DeviceBuffer of >= 4n elements"""
+        a = QuotientArgs()
+        for i in range(3):
+            a.wires[i] = wires[i].handle.value
+            a.sigma[i] = sigma[i].handle.value
+        a.z = z.handle.value
+        for i in range(5):
+            a.selectors[i] = selectors[i].handle.value
+        a.public_inputs = pi.handle.value
+        for name, val in (("alpha", alpha), ("beta", beta), ("gamma", gamma)):
+            arr = getattr(a, name)
+            for j, limb in enumerate(np.asarray(val, dtype=np.uint64).reshape(4)):
+                arr[j] = int(limb)
+        for i in range(3):
+            for j, limb in enumerate(np.asarray(cosets[i], dtype=np.uint64).reshape(4)):
+                a.cosets[i][j] = int(limb)
+        self._chk(self.lib.typlonk_quotient_dev(self.h, C.byref(a), log_n, t_out.handle))
 
     def alloc(self, n: int) -> DeviceBuffer:
         return DeviceBuffer(self, n)

@@ -74,7 +74,7 @@ struct typlonk_ctx {
     hipStream_t stream2 = nullptr;  // second lane of typlonk_msm_g1_batch*
     hipEvent_t batch_evt = nullptr;
     // NTT
-    DevBuf ntt_scratch, ntt_io;
+    DevBuf ntt_scratch, ntt_io, quot_ext;
     std::map<std::string, Table> tables;
     // profiling
     bool profiling = false;
@@ -652,7 +652,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     prof_begin(ctx);
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
-    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io}) release(*b);
+    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (DevBuf* b : {&ws.keys, &ws.sorted, &ws.counts, &ws.offsets, &ws.cursor, &ws.blocksums, &ws.buckets, &ws.part_a,
                           &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base})
@@ -829,6 +829,86 @@ int typlonk_ntt_fr(typlonk_ctx* ctx, uint64_t* data, uint32_t log_n, int inverse
     HIPCHK(hipMemcpyAsync(data, ctx->ntt_io.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return TYPLONK_OK;
+}
+
+int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out) {
+    if (!ctx || !args || !t_out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (log_n < 1 || log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 30");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n, n4 = 4 * n;
+    const uint32_t log4 = log_n + 2;
+    const typlonk_buf* in[13] = {args->wires[0], args->wires[1], args->wires[2], args->z,
+                                 args->selectors[0], args->selectors[1], args->selectors[2], args->selectors[3],
+                                 args->selectors[4], args->sigma[0], args->sigma[1], args->sigma[2], args->public_inputs};
+    for (const typlonk_buf* b : in)
+        if (!b || b->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "quotient input shorter than n");
+    if (t_out->n < n4) return fail(ctx, TYPLONK_ERR_RANGE, "t_out must hold 4n elements");
+    int rc = ensure(ctx, ctx->quot_ext, 14 * n4 * sizeof(Fr));
+    if (rc) return rc;
+    Fr* ext = (Fr*)ctx->quot_ext.p;
+    hipStream_t s = ctx->stream;
+    // coset generator: Fr's multiplicative generator 7 (7^(4n) != 1, so X^n - 1 never vanishes on g*H_4n)
+    const Fr g = fr_from_u64(7);
+    uint64_t g_limbs[4];
+    memcpy(g_limbs, g.v, sizeof(g_limbs));
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;
+    // 13 inputs + L0 = (1/n) sum X^i : zero-extend to 4n and evaluate on the coset
+    for (int k = 0; k < 14 && !rc; ++k) {
+        Fr* e = ext + (uint64_t)k * n4;
+        if (k < 13) {
+            HIPCHK(hipMemcpyAsync(e, in[k]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+        } else {
+            launch_fr_fill(e, n, fe_inv(fr_from_u64(n)), s);
+        }
+        HIPCHK(hipMemsetAsync(e + n, 0, (n4 - n) * sizeof(Fr), s));
+        rc = ntt_run(ctx, e, log4, 0, g_limbs);
+    }
+    if (rc) {
+        ctx->profiling = prof;
+        return rc;
+    }
+    QuotientArgs qa{};
+    for (int k = 0; k < 3; ++k) qa.wires[k] = ext + (uint64_t)k * n4;
+    qa.z = ext + 3 * n4;
+    for (int k = 0; k < 5; ++k) qa.sel[k] = ext + (uint64_t)(4 + k) * n4;
+    for (int k = 0; k < 3; ++k) qa.sigma[k] = ext + (uint64_t)(9 + k) * n4;
+    qa.pi = ext + 12 * n4;
+    qa.l0 = ext + 13 * n4;
+    qa.out = t_out->d;
+    qa.n4 = n4;
+    {
+        Table lo, hi;
+        const Fr w4 = fr_domain_root(log4);
+        rc = get_pow2l(ctx, "tw:f:" + std::to_string(log4), w4, Fr::one(), log4, &lo, &hi, &qa.w_h);
+        if (rc) {
+            ctx->profiling = prof;
+            return rc;
+        }
+        qa.w_lo = lo.d;
+        qa.w_hi = hi.d;
+        // X^n - 1 on the coset: g^n * iota^k - 1 with iota = w_{4n}^n (a primitive 4th root of unity)
+        Fr gn = g;
+        for (uint32_t i = 0; i < log_n; ++i) gn = fe_sqr(gn);
+        Fr iota = w4;
+        for (uint32_t i = 0; i < log_n; ++i) iota = fe_sqr(iota);
+        Fr cur = gn;
+        for (int k = 0; k < 4; ++k) {
+            qa.zh_inv[k] = fe_inv(fe_sub(cur, Fr::one()));
+            cur = fe_mul(cur, iota);
+        }
+    }
+    qa.g = g;
+    memcpy(qa.alpha.v, args->alpha, 32);
+    memcpy(qa.beta.v, args->beta, 32);
+    memcpy(qa.gamma.v, args->gamma, 32);
+    qa.alpha2 = fe_sqr(qa.alpha);
+    for (int k = 0; k < 3; ++k) memcpy(qa.k[k].v, args->cosets[k], 32);
+    launch_quotient_pointwise(qa, s);
+    HIPCHK(hipGetLastError());
+    rc = ntt_run(ctx, t_out->d, log4, 1, g_limbs);
+    ctx->profiling = prof;
+    return rc;
 }
 
 int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out) {

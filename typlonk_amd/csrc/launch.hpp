@@ -15,6 +15,26 @@ constexpr int MSM_SEG = 8;            // buckets per reduce thread
 // of msm_accum_kernel: 3.9 GB -> see profiles/).
 constexpr int PT_WORDS = 32;
 
+// arguments of the quotient pointwise kernel (quotient.hip): every array holds 4n coset evaluations
+struct QuotientArgs {
+    const Fr* wires[3];
+    const Fr* z;
+    const Fr* sel[5];  // q_l q_r q_o q_m q_c
+    const Fr* sigma[3];
+    const Fr* pi;
+    const Fr* l0;
+    const Fr* w_lo;    // powers of w_{4n}: lo[e & mask] * hi[e >> w_h]
+    const Fr* w_hi;
+    Fr* out;
+    uint64_t n4;
+    uint32_t w_h;
+    Fr g, alpha, alpha2, beta, gamma;
+    Fr k[3];
+    Fr zh_inv[4];      // 1 / (g^n * i^k - 1), k = index mod 4
+};
+void launch_fr_fill(Fr* out, uint64_t n, const Fr& value, hipStream_t s);
+void launch_quotient_pointwise(const QuotientArgs& a, hipStream_t s);
+
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s);
 
 void launch_convert_points(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);
