@@ -87,7 +87,10 @@ int typlonk_msm_g1_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* c
  * omega = TWO_ADIC_ROOT_OF_UNITY^(2^(32-log_n)).  Natural order in, natural order out, in place.
  *   inverse = 0: data[k] <- sum_i data[i] * (g*omega^k)^i                (fft / coset_fft)
  *   inverse = 1: data[i] <- g^-i * n^-1 * sum_k data[k] * omega^(-ik)    (ifft / coset_ifft)
- * coset_shift: NULL (g = 1) or 4 limbs (Montgomery).  The caller zero-pads to 2^log_n. */
+ * coset_shift: NULL (g = 1) or 4 limbs (Montgomery).  The caller zero-pads to 2^log_n.
+ * typlonk_ntt_fr blocks until the result is back on the host; the _dev / _devptr forms (and
+ * typlonk_quotient_dev) are stream-ordered on the context's stream and return once enqueued -- any
+ * later call on the same context, a typlonk_buf_download or typlonk_sync observes the result. */
 int typlonk_ntt_fr(typlonk_ctx* ctx, uint64_t* data, uint32_t log_n, int inverse, const uint64_t* coset_shift);
 int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32_t log_n, int inverse,
                        const uint64_t* coset_shift);
@@ -113,7 +116,13 @@ typedef struct typlonk_quotient_args {
     const typlonk_buf* public_inputs;
     uint64_t alpha[4], beta[4], gamma[4];
     uint64_t cosets[3][4];
+    uint32_t circuit; /* 0, or an id from typlonk_circuit_load: selectors/sigma above are then ignored */
 } typlonk_quotient_args;
+/* Transform the per-circuit constants of the quotient (five selector + three sigma polynomials, and
+ * L0) to the 4n coset domain once; they are fixed per CompiledCircuit (plonk/src/lib.rs:19-35). */
+int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5], const typlonk_buf* const sigma[3],
+                         uint32_t log_n, uint32_t* circuit_id);
+int typlonk_circuit_free(typlonk_ctx* ctx, uint32_t circuit_id);
 int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out);
 
 /* ---- device-resident Fr vectors (so an iNTT result feeds an MSM without crossing PCIe) ---------- */

@@ -90,6 +90,28 @@ def test_quotient_identity_at_2_12(ctx):
         assert O.poly_eval(t, x) * zh % O.R == num
 
 
+def test_quotient_with_cached_circuit(ctx):
+    """typlonk_circuit_load caches the per-circuit coset evaluations; two proofs (different witnesses,
+    different challenges) against one loaded circuit equal the uncached results"""
+    log_n, n = 6, 64
+    r1 = PO.prove_round_2_3(log_n, ALPHA, BETA, GAMMA, x0=3)
+    sel = [_upload(ctx, r1["q"][k], n) for k in ("q_l", "q_r", "q_o", "q_m", "q_c")]
+    sig = [_upload(ctx, s, n) for s in r1["sigma"]]
+    cid = ctx.circuit_load(log_n, sel, sig)
+    for b in sel + sig:
+        b.free()       # the circuit keeps its own transformed copies
+    for x0, (al, be, ga) in ((3, (ALPHA, BETA, GAMMA)), (0x77, (5, 6, 7))):
+        r = PO.prove_round_2_3(log_n, al, be, ga, x0=x0)
+        wires = [_upload(ctx, w, n) for w in r["wires"]]
+        z, pi, t_out = _upload(ctx, r["z"], n), _upload(ctx, r["pi"], n), ctx.alloc(4 * n)
+        ctx.quotient_dev(log_n, wires, z, None, None, pi, _limbs(al), _limbs(be), _limbs(ga),
+                         [_limbs(k) for k in PO.COSETS], t_out, circuit=cid)
+        assert O.poly_trim(fr_unpack(t_out.download())) == r["t"]
+        for b in wires + [z, pi, t_out]:
+            b.free()
+    ctx.circuit_free(cid)
+
+
 def test_quotient_argument_errors(ctx):
     from typlonk_amd.capi import TyplonkError, ERR_RANGE
 

@@ -19,7 +19,7 @@ SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
-    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
@@ -36,7 +36,7 @@ class QuotientArgs(C.Structure):
     """typlonk_quotient_args"""
     _fields_ = [("wires", C.c_void_p * 3), ("z", C.c_void_p), ("selectors", C.c_void_p * 5), ("sigma", C.c_void_p * 3),
                 ("public_inputs", C.c_void_p), ("alpha", C.c_uint64 * 4), ("beta", C.c_uint64 * 4),
-                ("gamma", C.c_uint64 * 4), ("cosets", (C.c_uint64 * 4) * 3)]
+                ("gamma", C.c_uint64 * 4), ("cosets", (C.c_uint64 * 4) * 3), ("circuit", C.c_uint32)]
 
 
 _lib = None
@@ -74,6 +74,8 @@ def load_library() -> C.CDLL:
     lib.typlonk_ntt_fr_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_devptr.argtypes = [vp, vp, C.c_uint32, C.c_int, u64p]
     lib.typlonk_quotient_dev.argtypes = [vp, C.POINTER(QuotientArgs), C.c_uint32, vp]
+    lib.typlonk_circuit_load.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.typlonk_circuit_free.argtypes = [vp, C.c_uint32]
     lib.typlonk_buf_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.typlonk_buf_free.argtypes = [vp, vp]
     lib.typlonk_buf_upload.argtypes = [vp, vp, C.c_size_t, u64p, C.c_size_t]
@@ -284,16 +286,29 @@ class Context:
         keep, cp = self._coset(coset)
         self._chk(self.lib.typlonk_ntt_fr_devptr(self.h, devptr, log_n, int(inverse), cp))
 
-    def quotient_dev(self, log_n: int, wires, z, selectors, sigma, pi, alpha, beta, gamma, cosets, t_out):
+    def circuit_load(self, log_n: int, selectors, sigma) -> int:
+        sel = (C.c_void_p * 5)(*[b.handle.value for b in selectors])
+        sig = (C.c_void_p * 3)(*[b.handle.value for b in sigma])
+        cid = C.c_uint32()
+        self._chk(self.lib.typlonk_circuit_load(self.h, sel, sig, log_n, C.byref(cid)))
+        return cid.value
+
+    def circuit_free(self, cid: int):
+        self._chk(self.lib.typlonk_circuit_free(self.h, cid))
+
+    def quotient_dev(self, log_n: int, wires, z, selectors, sigma, pi, alpha, beta, gamma, cosets, t_out, circuit=0):
         """typlonk_quotient_dev: all polynomial arguments are DeviceBuffers (n coefficients), scalars are
         4-limb Montgomery arrays; t_out is a DeviceBuffer of >= 4n elements"""
         a = QuotientArgs()
+        a.circuit = circuit
         for i in range(3):
             a.wires[i] = wires[i].handle.value
-            a.sigma[i] = sigma[i].handle.value
+            if not circuit:
+                a.sigma[i] = sigma[i].handle.value
         a.z = z.handle.value
         for i in range(5):
-            a.selectors[i] = selectors[i].handle.value
+            if not circuit:
+                a.selectors[i] = selectors[i].handle.value
         a.public_inputs = pi.handle.value
         for name, val in (("alpha", alpha), ("beta", beta), ("gamma", gamma)):
             arr = getattr(a, name)

@@ -34,6 +34,14 @@ struct Table {
     size_t n = 0;
 };
 
+// Per-circuit constants of the quotient: the 4n coset evaluations of q_l q_r q_o q_m q_c, sigma_0..2
+// and L0 (9 vectors).  They are fixed per CompiledCircuit (plonk/src/lib.rs:19-35), so they are
+// transformed once instead of on every proof.
+struct CircuitEntry {
+    Fr* ext = nullptr;  // 9 * 4n
+    uint32_t log_n = 0;
+};
+
 struct ProfStage {
     const char* name;
     hipEvent_t a, b;
@@ -68,6 +76,8 @@ struct typlonk_ctx {
     std::string err;
     std::map<uint32_t, SrsEntry> srs;
     uint32_t next_srs = 1;
+    std::map<uint32_t, CircuitEntry> circuits;
+    uint32_t next_circuit = 1;
     // MSM
     DevBuf scal;
     MsmWs ws[2];
@@ -241,7 +251,7 @@ uint32_t ilog2_u64(uint64_t x) {
     return r;
 }
 
-int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift) {
+int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift, bool sync = true) {
     if (log_n > 32) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 32 (Fr two-adicity)");
     if (!d_data) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null data");
     prof_begin(ctx);
@@ -359,7 +369,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         rows *= M;
         row_len /= M;
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (sync || ctx->profiling) HIPCHK(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     return TYPLONK_OK;
 }
@@ -651,6 +661,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     prof_begin(ctx);
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
+    for (auto& kv : ctx->circuits) (void)hipFree(kv.second.ext);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
     for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext}) release(*b);
     for (MsmWs& ws : ctx->ws) {
@@ -803,7 +814,7 @@ int typlonk_msm_g1(typlonk_ctx* ctx, uint32_t srs_id, const uint64_t* scalars, s
 int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift) {
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(ctx->device));
-    return ntt_run(ctx, (Fr*)d_data, log_n, inverse, coset_shift);
+    return ntt_run(ctx, (Fr*)d_data, log_n, inverse, coset_shift, /*sync=*/false);
 }
 
 int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32_t log_n, int inverse,
@@ -813,7 +824,7 @@ int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32
     const uint64_t N = 1ull << log_n;
     if (offset > buf->n || N > buf->n - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside buffer");
     HIPCHK(hipSetDevice(ctx->device));
-    return ntt_run(ctx, buf->d + offset, log_n, inverse, coset_shift);
+    return ntt_run(ctx, buf->d + offset, log_n, inverse, coset_shift, /*sync=*/false);
 }
 
 int typlonk_ntt_fr(typlonk_ctx* ctx, uint64_t* data, uint32_t log_n, int inverse, const uint64_t* coset_shift) {
@@ -831,39 +842,106 @@ int typlonk_ntt_fr(typlonk_ctx* ctx, uint64_t* data, uint32_t log_n, int inverse
     return TYPLONK_OK;
 }
 
+namespace {
+const uint64_t* quotient_coset_g(Fr* g_out) {
+    // coset generator: Fr's multiplicative generator 7 (7^(4n) != 1, so X^n - 1 never vanishes on g*H_4n)
+    static uint64_t limbs[4];
+    const Fr g = fr_from_u64(7);
+    memcpy(limbs, g.v, sizeof(limbs));
+    if (g_out) *g_out = g;
+    return limbs;
+}
+
+// zero-extend an n-coefficient vector (or the constant-coefficient polynomial `fill`) to 4n and
+// evaluate it on the coset g*H_4n, in place in `e`
+int quotient_extend(typlonk_ctx* ctx, Fr* e, const Fr* src, const Fr* fill, uint64_t n, uint32_t log4) {
+    hipStream_t s = ctx->stream;
+    if (src) {
+        HIPCHK(hipMemcpyAsync(e, src, n * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+    } else {
+        launch_fr_fill(e, n, *fill, s);
+    }
+    HIPCHK(hipMemsetAsync(e + n, 0, 3 * n * sizeof(Fr), s));
+    return ntt_run(ctx, e, log4, 0, quotient_coset_g(nullptr), /*sync=*/false);
+}
+}  // namespace
+
+int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5], const typlonk_buf* const sigma[3],
+                         uint32_t log_n, uint32_t* circuit_id) {
+    if (!ctx || !selectors || !sigma || !circuit_id) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (log_n < 1 || log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 30");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n, n4 = 4 * n;
+    const typlonk_buf* in[8] = {selectors[0], selectors[1], selectors[2], selectors[3], selectors[4],
+                                sigma[0], sigma[1], sigma[2]};
+    for (const typlonk_buf* b : in)
+        if (!b || b->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "circuit polynomial shorter than n");
+    CircuitEntry e;
+    e.log_n = log_n;
+    HIPCHK(hipMalloc((void**)&e.ext, 9 * n4 * sizeof(Fr)));
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;
+    int rc = TYPLONK_OK;
+    const Fr ninv = fe_inv(fr_from_u64(n));
+    for (int k = 0; k < 9 && !rc; ++k)
+        rc = quotient_extend(ctx, e.ext + (uint64_t)k * n4, k < 8 ? in[k]->d : nullptr, &ninv, n, log_n + 2);
+    ctx->profiling = prof;
+    if (!rc) {
+        hipError_t he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
+    }
+    if (rc) {
+        (void)hipFree(e.ext);
+        return rc;
+    }
+    const uint32_t id = ctx->next_circuit++;
+    ctx->circuits[id] = e;
+    *circuit_id = id;
+    return TYPLONK_OK;
+}
+
+int typlonk_circuit_free(typlonk_ctx* ctx, uint32_t circuit_id) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    auto it = ctx->circuits.find(circuit_id);
+    if (it == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(it->second.ext));
+    ctx->circuits.erase(it);
+    return TYPLONK_OK;
+}
+
 int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out) {
     if (!ctx || !args || !t_out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
     if (log_n < 1 || log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 30");
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n, n4 = 4 * n;
     const uint32_t log4 = log_n + 2;
-    const typlonk_buf* in[13] = {args->wires[0], args->wires[1], args->wires[2], args->z,
+    // per-proof inputs first, then (without a cached circuit) the per-circuit ones
+    const typlonk_buf* in[13] = {args->wires[0], args->wires[1], args->wires[2], args->z, args->public_inputs,
                                  args->selectors[0], args->selectors[1], args->selectors[2], args->selectors[3],
-                                 args->selectors[4], args->sigma[0], args->sigma[1], args->sigma[2], args->public_inputs};
-    for (const typlonk_buf* b : in)
-        if (!b || b->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "quotient input shorter than n");
+                                 args->selectors[4], args->sigma[0], args->sigma[1], args->sigma[2]};
+    const Fr* cached = nullptr;
+    if (args->circuit) {
+        auto it = ctx->circuits.find(args->circuit);
+        if (it == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
+        if (it->second.log_n != log_n) return fail(ctx, TYPLONK_ERR_DOMAIN, "circuit was loaded for another domain size");
+        cached = it->second.ext;
+    }
+    const int n_in = cached ? 5 : 13;
+    for (int k = 0; k < n_in; ++k)
+        if (!in[k] || in[k]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "quotient input shorter than n");
     if (t_out->n < n4) return fail(ctx, TYPLONK_ERR_RANGE, "t_out must hold 4n elements");
-    int rc = ensure(ctx, ctx->quot_ext, 14 * n4 * sizeof(Fr));
+    int rc = ensure(ctx, ctx->quot_ext, (size_t)(cached ? 5 : 14) * n4 * sizeof(Fr));
     if (rc) return rc;
     Fr* ext = (Fr*)ctx->quot_ext.p;
     hipStream_t s = ctx->stream;
-    // coset generator: Fr's multiplicative generator 7 (7^(4n) != 1, so X^n - 1 never vanishes on g*H_4n)
-    const Fr g = fr_from_u64(7);
-    uint64_t g_limbs[4];
-    memcpy(g_limbs, g.v, sizeof(g_limbs));
+    Fr g;
+    const uint64_t* g_limbs = quotient_coset_g(&g);
     const bool prof = ctx->profiling;
     ctx->profiling = false;
-    // 13 inputs + L0 = (1/n) sum X^i : zero-extend to 4n and evaluate on the coset
-    for (int k = 0; k < 14 && !rc; ++k) {
-        Fr* e = ext + (uint64_t)k * n4;
-        if (k < 13) {
-            HIPCHK(hipMemcpyAsync(e, in[k]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s));
-        } else {
-            launch_fr_fill(e, n, fe_inv(fr_from_u64(n)), s);
-        }
-        HIPCHK(hipMemsetAsync(e + n, 0, (n4 - n) * sizeof(Fr), s));
-        rc = ntt_run(ctx, e, log4, 0, g_limbs);
-    }
+    const Fr ninv = fe_inv(fr_from_u64(n));
+    for (int k = 0; k < (cached ? 5 : 14) && !rc; ++k)
+        rc = quotient_extend(ctx, ext + (uint64_t)k * n4, k < 13 ? in[k]->d : nullptr, &ninv, n, log4);
     if (rc) {
         ctx->profiling = prof;
         return rc;
@@ -871,10 +949,11 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     QuotientArgs qa{};
     for (int k = 0; k < 3; ++k) qa.wires[k] = ext + (uint64_t)k * n4;
     qa.z = ext + 3 * n4;
-    for (int k = 0; k < 5; ++k) qa.sel[k] = ext + (uint64_t)(4 + k) * n4;
-    for (int k = 0; k < 3; ++k) qa.sigma[k] = ext + (uint64_t)(9 + k) * n4;
-    qa.pi = ext + 12 * n4;
-    qa.l0 = ext + 13 * n4;
+    qa.pi = ext + 4 * n4;
+    const Fr* cbase = cached ? cached : ext + 5 * n4;
+    for (int k = 0; k < 5; ++k) qa.sel[k] = cbase + (uint64_t)k * n4;
+    for (int k = 0; k < 3; ++k) qa.sigma[k] = cbase + (uint64_t)(5 + k) * n4;
+    qa.l0 = cbase + 8 * n4;
     qa.out = t_out->d;
     qa.n4 = n4;
     {
@@ -906,7 +985,7 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     for (int k = 0; k < 3; ++k) memcpy(qa.k[k].v, args->cosets[k], 32);
     launch_quotient_pointwise(qa, s);
     HIPCHK(hipGetLastError());
-    rc = ntt_run(ctx, t_out->d, log4, 1, g_limbs);
+    rc = ntt_run(ctx, t_out->d, log4, 1, g_limbs, /*sync=*/false);
     ctx->profiling = prof;
     return rc;
 }
