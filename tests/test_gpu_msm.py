@@ -229,3 +229,37 @@ def test_batch_matches_individual_msms(ctx):
     for b, _ in bufs:
         b.free()
     ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("name", ["ones", "repeated", "alternating", "short", "two_values"])
+def test_adversarial_scalars_at_2_16_use_heavy_bucket_tasks(ctx, name):
+    """SURVEY section 8d adversarial sets at a size where a single bucket receives up to m entries: the
+    heavy-bucket task splitting must give the exact result (and finish quickly)."""
+    import time
+    from oracle import coracle as CO
+
+    m = 1 << 16
+    s_limbs = np.array(O.fr_to_mont_limbs(2), dtype=np.uint64)
+    sid = ctx.srs_generate(s_limbs, m + 3)
+    rep = O.random_frs(4242, 2)
+    vals = {
+        "ones": lambda i: 1,
+        "repeated": lambda i: rep[0],
+        "alternating": lambda i: 0 if i % 2 else O.R - 1,
+        "short": lambda i: (i * 2654435761) & 0xFF,
+        "two_values": lambda i: rep[i % 2],
+    }[name]
+    uniq = {}
+    sc = np.empty((m, 4), dtype=np.uint64)
+    for i in range(m):
+        v = vals(i)
+        if v not in uniq:
+            uniq[v] = O.fr_to_mont_limbs(v)
+        sc[i] = uniq[v]
+    t0 = time.time()
+    out, inf = ctx.msm(sid, sc)
+    dt = time.time() - t0
+    exp, einf = CO.g1_mul_generator(CO.poly_eval(sc, s_limbs))
+    assert (out == exp).all() and inf == einf
+    assert dt < 5.0, f"adversarial MSM took {dt:.1f} s"
+    ctx.srs_free(sid)

@@ -53,7 +53,8 @@ struct ProfStage {
 // plonk/src/proof.rs:107-110, 147-175, 181) can overlap one MSM's host-side finish (window combine, affine
 // normalisation) and kernel tail with the next one's sort + accumulate.
 struct MsmWs {
-    DevBuf keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist, blk_hist, blk_base;
+    DevBuf keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist, blk_hist, blk_base, heavy, tasks,
+        hpart;
     hipStream_t stream = nullptr;
     uint32_t* host_wins = nullptr;  // pinned, 64 windows x 48 words
     bool pending = false;
@@ -448,7 +449,13 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     if ((rc = ensure(ctx, ws.blocksums, (size_t)scan_blocks * 4))) return rc;
     if ((rc = ensure(ctx, ws.buckets, nb * 192))) return rc;
     if ((rc = ensure(ctx, ws.order, nb * 4))) return rc;
-    if ((rc = ensure(ctx, ws.ohist, 512 * 4))) return rc;
+    if ((rc = ensure(ctx, ws.ohist, 514 * 4))) return rc;
+    // heavy-bucket splitting: cap = entries one thread may sum; at most total/cap heavy buckets/tasks
+    const uint32_t cap = (uint32_t)std::max<uint64_t>(512, 4 * ((total + nb - 1) / nb));
+    const uint64_t max_tasks = total / cap + 2;
+    if ((rc = ensure(ctx, ws.heavy, max_tasks * 12))) return rc;
+    if ((rc = ensure(ctx, ws.tasks, max_tasks * 8))) return rc;
+    if ((rc = ensure(ctx, ws.hpart, max_tasks * 192))) return rc;
     if ((rc = ensure(ctx, ws.part_a, (size_t)nodes * 192))) return rc;
     if ((rc = ensure(ctx, ws.part_b, (size_t)nodes * 192))) return rc;
 
@@ -497,11 +504,14 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     }
     {
         StageTimer st(ctx, "msm_order", s);
-        launch_bucket_order(counts, (uint32_t)nb, (uint32_t*)ws.ohist.p, (uint32_t*)ws.order.p, s);
+        launch_bucket_order(counts, offsets, (uint32_t)nb, cap, (uint32_t*)ws.ohist.p, (uint32_t*)ws.order.p,
+                            (uint32_t*)ws.heavy.p, (uint32_t*)ws.tasks.p, s);
     }
     {
         StageTimer st(ctx, "msm_accum", s);
-        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ws.order.p, (uint32_t)nb, buckets, s);
+        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ws.order.p, (uint32_t)nb, cap, buckets, s);
+        launch_msm_heavy(srs.d_points, sorted, (const uint32_t*)ws.ohist.p, (const uint32_t*)ws.heavy.p,
+                         (const uint32_t*)ws.tasks.p, (uint32_t*)ws.hpart.p, buckets, s);
     }
     uint32_t* cur = pa;
     uint32_t* other = pb;
@@ -666,7 +676,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (DevBuf* b : {&ws.keys, &ws.sorted, &ws.counts, &ws.offsets, &ws.cursor, &ws.blocksums, &ws.buckets, &ws.part_a,
-                          &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base})
+                          &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base, &ws.heavy, &ws.tasks, &ws.hpart})
             release(*b);
         if (ws.host_wins) (void)hipHostFree(ws.host_wins);
     }

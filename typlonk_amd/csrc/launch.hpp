@@ -45,11 +45,14 @@ void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint3
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t* blk_hist, uint32_t* blk_base, uint32_t* scan_scratch, uint32_t* entries,
                         uint32_t* counts, uint32_t* offsets, uint32_t* sorted, hipStream_t s);
-void launch_bucket_order(const uint32_t* counts, uint32_t n, uint32_t* hist512, uint32_t* order, hipStream_t s);
+void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
+                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, hipStream_t s);
+void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist514, const uint32_t* heavy,
+                      const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s);
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
                         hipStream_t s);
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
-                      uint32_t nbuckets, uint32_t* buckets, hipStream_t s);
+                      uint32_t nbuckets, uint32_t cap, uint32_t* buckets, hipStream_t s);
 void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
                        uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s);
 void launch_msm_fold(const uint32_t* in, uint32_t total, uint32_t group, uint32_t* out, hipStream_t s);

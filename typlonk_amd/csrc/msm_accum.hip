@@ -32,11 +32,12 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_kernel(const uint32
                                                                     const uint32_t* __restrict__ offsets,
                                                                     const uint32_t* __restrict__ sorted,
                                                                     const uint32_t* __restrict__ order,
-                                                                    uint32_t nbuckets, uint32_t* buckets) {
+                                                                    uint32_t nbuckets, uint32_t cap, uint32_t* buckets) {
     const uint32_t t = blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t >= nbuckets) return;
     const uint32_t g = order[t];
-    const uint32_t start = offsets[g], end = offsets[g + 1];
+    const uint32_t start = offsets[g];
+    const uint32_t end = min(offsets[g + 1], start + cap);  // the tail of a heavy bucket goes to msm_heavy_kernel
     G1Xyzz acc = G1Xyzz::inf();
     uint32_t pl_next = 0;
     PackedPoint pk_next;
@@ -56,10 +57,43 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_kernel(const uint32
     st_xyzz(buckets, g, acc);
 }
 
+// tasks of heavy buckets, one per thread, grid-strided (the task count lives on the device)
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_kernel(const uint32_t* __restrict__ points,
+                                                                    const uint32_t* __restrict__ sorted,
+                                                                    const uint32_t* __restrict__ hist514,
+                                                                    const uint32_t* __restrict__ tasks, uint32_t* partial) {
+    const uint32_t ntasks = hist514[513];
+    for (uint32_t t = blockIdx.x * MSM_ACC_THREADS + threadIdx.x; t < ntasks; t += gridDim.x * MSM_ACC_THREADS) {
+        G1Xyzz acc = G1Xyzz::inf();
+        for (uint32_t pos = tasks[2 * t]; pos < tasks[2 * t + 1]; ++pos) {
+            const uint32_t pl = sorted[pos];
+            g1_madd(acc, unpack_point(ld_packed(points, pl & 0x7fffffffu)), (pl >> 31) != 0);
+        }
+        st_xyzz(partial, t, acc);
+    }
+}
+// one thread per heavy bucket: bucket += sum of its task partials
+__global__ __launch_bounds__(64) void msm_heavy_combine_kernel(const uint32_t* __restrict__ hist514,
+                                                               const uint32_t* __restrict__ heavy,
+                                                               const uint32_t* __restrict__ partial, uint32_t* buckets) {
+    const uint32_t nheavy = hist514[512];
+    for (uint32_t h = blockIdx.x * 64 + threadIdx.x; h < nheavy; h += gridDim.x * 64) {
+        const uint32_t b = heavy[3 * h], t0 = heavy[3 * h + 1], k = heavy[3 * h + 2];
+        G1Xyzz acc = ld_xyzz(buckets, b);
+        for (uint32_t t = 0; t < k; ++t) acc = g1_add(acc, ld_xyzz(partial, t0 + t));
+        st_xyzz(buckets, b, acc);
+    }
+}
+
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
-                      uint32_t nbuckets, uint32_t* buckets, hipStream_t s) {
+                      uint32_t nbuckets, uint32_t cap, uint32_t* buckets, hipStream_t s) {
     hipLaunchKernelGGL(msm_accum_kernel, dim3((nbuckets + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), dim3(MSM_ACC_THREADS), 0,
-                       s, points, offsets, sorted, order, nbuckets, buckets);
+                       s, points, offsets, sorted, order, nbuckets, cap, buckets);
+}
+void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist514, const uint32_t* heavy,
+                      const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s) {
+    hipLaunchKernelGGL(msm_heavy_kernel, dim3(2048), dim3(MSM_ACC_THREADS), 0, s, points, sorted, hist514, tasks, partial);
+    hipLaunchKernelGGL(msm_heavy_combine_kernel, dim3(64), dim3(64), 0, s, hist514, heavy, partial, buckets);
 }
 
 }  // namespace ty

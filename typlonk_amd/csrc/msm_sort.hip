@@ -286,12 +286,37 @@ __global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __res
 // A wave's 64 lanes run their buckets in lock step, so its time is the LARGEST of its 64 bucket
 // sizes; handing each wave buckets of (nearly) equal size removes that imbalance.  Counting sort on
 // min(count, 255): LDS-privatised histogram per block, one global atomic per (block, bin).
-__global__ __launch_bounds__(256) void order_hist_kernel(const uint32_t* counts, uint32_t n, uint32_t* hist) {
+//
+// Heavy buckets.  A bucket with more than `cap` entries (only adversarial inputs produce them: equal
+// scalars, tiny scalars, ...) would be summed by a single thread; instead the accumulate kernel takes
+// its first `cap` entries and the rest is cut into tasks of <= cap entries that msm_heavy_kernel
+// spreads over the whole chip.  hist[512] = number of heavy buckets, hist[513] = number of tasks;
+// heavy[3h..3h+2] = (bucket, first task, task count); tasks[2t..2t+1] = (begin, end) in `sorted`.
+__global__ __launch_bounds__(256) void order_hist_kernel(const uint32_t* counts, const uint32_t* offsets, uint32_t n,
+                                                         uint32_t cap, uint32_t* hist, uint32_t* heavy, uint32_t* tasks) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g < n) atomicAdd(&h[min(counts[g], 255u)], 1u);
+    if (g < n) {
+        const uint32_t cnt = counts[g];
+        atomicAdd(&h[min(cnt, 255u)], 1u);
+        if (cnt > cap) {
+            const uint32_t k = (cnt - cap + cap - 1) / cap;
+            const uint32_t hi = atomicAdd(&hist[512], 1u);
+            const uint32_t t0 = atomicAdd(&hist[513], k);
+            heavy[3 * hi] = g;
+            heavy[3 * hi + 1] = t0;
+            heavy[3 * hi + 2] = k;
+            uint32_t b = offsets[g] + cap;
+            const uint32_t e = offsets[g] + cnt;
+            for (uint32_t t = 0; t < k; ++t) {
+                tasks[2 * (t0 + t)] = b;
+                tasks[2 * (t0 + t) + 1] = min(b + cap, e);
+                b += cap;
+            }
+        }
+    }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
@@ -384,13 +409,14 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
                        offsets, sorted);
 }
 
-void launch_bucket_order(const uint32_t* counts, uint32_t n, uint32_t* hist512, uint32_t* order, hipStream_t s) {
-    // hist512: 512 u32 of scratch (histogram + running bases)
-    (void)hipMemsetAsync(hist512, 0, 512 * sizeof(uint32_t), s);
+void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
+                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, hipStream_t s) {
+    // hist514: histogram (256) + running bases (256) + heavy-bucket and task counters (2)
+    (void)hipMemsetAsync(hist514, 0, 514 * sizeof(uint32_t), s);
     const uint32_t nblk = (n + 255) / 256;
-    hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist512);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist512, hist512 + 256);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist512 + 256, order);
+    hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, offsets, n, cap, hist514, heavy, tasks);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist514, hist514 + 256);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514 + 256, order);
 }
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
                         hipStream_t s) {
