@@ -50,6 +50,19 @@ def synthetic_scalars(n: int, seed: int, device) -> torch.Tensor:
     return t
 
 
+def pmc_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/pmc_latest.json = separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
+    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; see tools/pmc_summary.py).
+    bench.py cannot run the profiler itself, so the value is null when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)[kernel]["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def prof_ms(ctx, name_prefix: str) -> float:
     return sum(ms for n, ms in ctx.profile() if n.startswith(name_prefix))
 
@@ -134,7 +147,10 @@ def main() -> None:
     if t_acc > 0:
         ach = alg_bytes / t_acc / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": pmc_traffic("ty::msm_accum_kernel") if world == 1 and log_n == 20 else None,
+                              "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, bytes per launch)",
+                              "algorithmic_bytes": alg_bytes,
                               "kernel_ms": t_acc * 1e3, "mixed_adds_per_s": W * m_local / t_acc,
                               "note": "integer-ALU-bound kernel; see DESIGN.md for the ALU roofline"}
 
