@@ -379,8 +379,11 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
 void msm_shape(typlonk_ctx* ctx, size_t m, uint32_t* c_out, uint32_t* w_out) {
     uint32_t lg = 0;  // ceil(log2 m)
     while (((size_t)1 << lg) < m) ++lg;
-    int c = (int)lg - 4;
-    if (c < 4) c = 4;
+    // measured on MI355X (tools/sweep_c.py): the best window is c ~ ceil(log2 m) clamped to [8, 16];
+    // the bucket reduction is a fixed ~50-operation dependent chain whatever c is, so small MSMs want
+    // many small buckets (short accumulate chains) rather than few windows
+    int c = (int)lg;
+    if (c < 8) c = 8;
     if (c > 16) c = 16;
     if (ctx && ctx->msm_c_override) c = ctx->msm_c_override;
     *c_out = (uint32_t)c;
