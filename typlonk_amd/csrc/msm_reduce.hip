@@ -39,12 +39,16 @@ __global__ __launch_bounds__(64) void msm_reduce_kernel(const uint32_t* __restri
             if (((s * L + l) & vmask) == 0) u = g1_add(u, running);
         }
         running = g1_add(running, ld_xyzz(buckets, base));
-        // w(k0) * S by double-and-add over cbits bits
+        // w(k0) * S with fixed 2-bit windows (table S, 2S, 3S): lanes hold different multipliers, so a
+        // bitwise double-and-add executes its conditional add at every position anyway; base 4 halves them
         const uint32_t kmul = ((s * L) >> wv) + 1;
+        const G1Xyzz s2 = g1_dbl(running);
+        const G1Xyzz s3 = g1_add(s2, running);
         G1Xyzz acc = G1Xyzz::inf();
-        for (int bit = (int)cbits - 1; bit >= 0; --bit) {
-            acc = g1_dbl(acc);
-            if ((kmul >> bit) & 1) acc = g1_add(acc, running);
+        for (int d = (int)(cbits + 1) / 2 - 1; d >= 0; --d) {
+            acc = g1_dbl(g1_dbl(acc));
+            const uint32_t dig = (kmul >> (2 * d)) & 3u;
+            if (dig) acc = g1_add(acc, dig == 1 ? running : (dig == 2 ? s2 : s3));
         }
         v = g1_add(u, acc);
     }
