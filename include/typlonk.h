@@ -125,6 +125,28 @@ int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5]
 int typlonk_circuit_free(typlonk_ctx* ctx, uint32_t circuit_id);
 int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out);
 
+/* ---- grand product Z of the copy-constraint argument (permutation::CompiledPermutation::prove,
+ * /root/reference/permutation/src/proving.rs:7-31, called at plonk/src/proof.rs:119-120).
+ * wires[i] / sigma[i]: the i-th witness column and sigma column as EVALUATIONS over the size-2^log_n
+ * domain (n elements each); cell (i, j) carries the identity tag cosets[i] * w^j.  z_evals_out receives
+ * Z_0 = 1, Z_j = prod_{k<j} prod_i (w_ik + beta id_ik + gamma) / (w_ik + beta sigma_ik + gamma), j < n
+ * (the reference's n+1 values without the last one).  Stream-ordered except for one 32-byte readback. */
+int typlonk_grand_product_dev(typlonk_ctx* ctx, const typlonk_buf* const wires[3], const typlonk_buf* const sigma[3],
+                              const uint64_t beta[4], const uint64_t gamma[4], const uint64_t cosets[3][4],
+                              uint32_t log_n, typlonk_buf* z_evals_out);
+
+/* ---- open(): the polynomial half of kzg::KzgScheme::open (/root/reference/kzg/src/lib.rs:55-61).
+ * poly: m coefficients starting at `offset` of a device vector.  y_out <- p(z) (Horner, :57); when
+ * q_out is not NULL it receives the m - 1 coefficients of (p - p(z)) / (X - z) (:58-61), ready for
+ * typlonk_msm_g1_dev (:62).  q_out must not alias poly.  1 <= m <= 2^22.  Blocks for the 32-byte result. */
+int typlonk_open_dev(typlonk_ctx* ctx, const typlonk_buf* poly, size_t offset, size_t m, const uint64_t z[4],
+                     typlonk_buf* q_out, uint64_t y_out[4]);
+/* out[i] = sum_k scalars[k] * polys[k][i] for i < n, plus `constant` (may be NULL) on coefficient 0: the
+ * scalar-times-polynomial sums of linearisation_poly (/root/reference/plonk/src/proof.rs:376-439).
+ * terms <= 12; every polys[k] holds >= n elements; out may alias none of them.  Stream-ordered. */
+int typlonk_lincomb_dev(typlonk_ctx* ctx, const typlonk_buf* const* polys, const uint64_t (*scalars)[4], size_t terms,
+                        const uint64_t* constant, size_t n, typlonk_buf* out);
+
 /* ---- device-resident Fr vectors (so an iNTT result feeds an MSM without crossing PCIe) ---------- */
 int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out);
 int typlonk_buf_free(typlonk_ctx* ctx, typlonk_buf* buf);

@@ -36,7 +36,7 @@ def hipcc_path() -> str:
     return p
 
 
-HIP_UNITS = ["capi.hip", "ntt_kernels.hip", "msm_sort.hip", "msm_accum.hip", "msm_reduce.hip", "srs_gen.hip", "quotient.hip"]
+HIP_UNITS = ["capi.hip", "ntt_kernels.hip", "msm_sort.hip", "msm_accum.hip", "msm_reduce.hip", "srs_gen.hip", "quotient.hip", "plonk_ops.hip"]
 
 
 def build_hip(force: bool = False) -> str:

@@ -19,7 +19,7 @@ SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
-    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
@@ -74,6 +74,10 @@ def load_library() -> C.CDLL:
     lib.typlonk_ntt_fr_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_devptr.argtypes = [vp, vp, C.c_uint32, C.c_int, u64p]
     lib.typlonk_quotient_dev.argtypes = [vp, C.POINTER(QuotientArgs), C.c_uint32, vp]
+    lib.typlonk_grand_product_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, u64p, C.POINTER((C.c_uint64 * 4) * 3),
+                                              C.c_uint32, vp]
+    lib.typlonk_open_dev.argtypes = [vp, vp, C.c_size_t, C.c_size_t, u64p, vp, u64p]
+    lib.typlonk_lincomb_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64 * 4), C.c_size_t, u64p, C.c_size_t, vp]
     lib.typlonk_circuit_load.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.typlonk_circuit_free.argtypes = [vp, C.c_uint32]
     lib.typlonk_buf_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -285,6 +289,39 @@ class Context:
     def ntt_devptr(self, devptr: int, log_n: int, inverse: bool = False, coset=None):
         keep, cp = self._coset(coset)
         self._chk(self.lib.typlonk_ntt_fr_devptr(self.h, devptr, log_n, int(inverse), cp))
+
+    def grand_product_dev(self, log_n: int, wire_evals, sigma_evals, beta, gamma, cosets, z_out):
+        """typlonk_grand_product_dev: column / sigma EVALUATIONS (DeviceBuffers) -> Z evaluations"""
+        w = (C.c_void_p * 3)(*[b.handle.value for b in wire_evals])
+        sg = (C.c_void_p * 3)(*[b.handle.value for b in sigma_evals])
+        be = np.ascontiguousarray(beta, dtype=np.uint64).reshape(4)
+        ga = np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4)
+        ks = ((C.c_uint64 * 4) * 3)()
+        for i in range(3):
+            for j, limb in enumerate(np.asarray(cosets[i], dtype=np.uint64).reshape(4)):
+                ks[i][j] = int(limb)
+        self._chk(self.lib.typlonk_grand_product_dev(self.h, w, sg, _u64p(be), _u64p(ga), C.byref(ks), log_n, z_out.handle))
+
+    def open_dev(self, poly: DeviceBuffer, m: int, z, q_out: DeviceBuffer | None = None, offset: int = 0) -> np.ndarray:
+        """typlonk_open_dev: returns y = p(z) (4 limbs); q_out receives (p - y)/(X - z) when given"""
+        zz = np.ascontiguousarray(z, dtype=np.uint64).reshape(4)
+        y = np.zeros(4, dtype=np.uint64)
+        self._chk(self.lib.typlonk_open_dev(self.h, poly.handle, offset, m, _u64p(zz), q_out.handle if q_out else None,
+                                            _u64p(y)))
+        return y
+
+    def lincomb_dev(self, polys, scalars, n: int, out: DeviceBuffer, constant=None):
+        k = len(polys)
+        ptrs = (C.c_void_p * max(k, 1))(*[b.handle.value for b in polys])
+        sc = ((C.c_uint64 * 4) * max(k, 1))()
+        for i, s in enumerate(scalars):
+            for j, limb in enumerate(np.asarray(s, dtype=np.uint64).reshape(4)):
+                sc[i][j] = int(limb)
+        cp = None
+        if constant is not None:
+            cc = np.ascontiguousarray(constant, dtype=np.uint64).reshape(4)
+            cp = _u64p(cc)
+        self._chk(self.lib.typlonk_lincomb_dev(self.h, ptrs, sc, k, cp, n, out.handle))
 
     def circuit_load(self, log_n: int, selectors, sigma) -> int:
         sel = (C.c_void_p * 5)(*[b.handle.value for b in selectors])

@@ -85,7 +85,7 @@ struct typlonk_ctx {
     hipStream_t stream2 = nullptr;  // second lane of typlonk_msm_g1_batch*
     hipEvent_t batch_evt = nullptr;
     // NTT
-    DevBuf ntt_scratch, ntt_io, quot_ext;
+    DevBuf ntt_scratch, ntt_io, quot_ext, ops_tmp;
     std::map<std::string, Table> tables;
     // profiling
     bool profiling = false;
@@ -676,7 +676,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
     for (auto& kv : ctx->circuits) (void)hipFree(kv.second.ext);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
-    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext}) release(*b);
+    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->ops_tmp}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (DevBuf* b : {&ws.keys, &ws.sorted, &ws.counts, &ws.offsets, &ws.cursor, &ws.blocksums, &ws.buckets, &ws.part_a,
                           &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base, &ws.heavy, &ws.tasks, &ws.hpart})
@@ -1001,6 +1001,107 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     rc = ntt_run(ctx, t_out->d, log4, 1, g_limbs, /*sync=*/false);
     ctx->profiling = prof;
     return rc;
+}
+
+int typlonk_grand_product_dev(typlonk_ctx* ctx, const typlonk_buf* const wires[3], const typlonk_buf* const sigma[3],
+                              const uint64_t beta[4], const uint64_t gamma[4], const uint64_t cosets[3][4],
+                              uint32_t log_n, typlonk_buf* z_evals_out) {
+    if (!ctx || !wires || !sigma || !beta || !gamma || !cosets || !z_evals_out)
+        return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 30");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t n = 1ull << log_n;
+    for (int i = 0; i < 3; ++i)
+        if (!wires[i] || !sigma[i] || wires[i]->n < n || sigma[i]->n < n)
+            return fail(ctx, TYPLONK_ERR_RANGE, "grand product input shorter than n");
+    if (z_evals_out->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "z_evals_out shorter than n");
+    const uint64_t nblk = (n + 2047) / 2048;
+    int rc = ensure(ctx, ctx->ops_tmp, (4 * n + nblk + 8) * sizeof(Fr));
+    if (rc) return rc;
+    Fr* num = (Fr*)ctx->ops_tmp.p;
+    Fr* den = num + n;
+    Fr* npre = den + n;
+    Fr* dsuf = npre + n;
+    Fr* blk = dsuf + n;
+    hipStream_t s = ctx->stream;
+    GrandProductArgs a{};
+    for (int i = 0; i < 3; ++i) {
+        a.wires[i] = wires[i]->d;
+        a.sigma[i] = sigma[i]->d;
+    }
+    a.num = num;
+    a.den = den;
+    a.n = n;
+    memcpy(a.beta.v, beta, 32);
+    memcpy(a.gamma.v, gamma, 32);
+    for (int i = 0; i < 3; ++i) {
+        Fr k;
+        memcpy(k.v, cosets[i], 32);
+        a.kbeta[i] = fe_mul(k, a.beta);
+    }
+    {
+        Table lo, hi;
+        const uint32_t lg = std::max<uint32_t>(log_n, 1);  // a two-level table needs at least one bit
+        rc = get_pow2l(ctx, "tw:f:" + std::to_string(lg), fr_domain_root(lg), Fr::one(), lg, &lo, &hi, &a.w_h);
+        if (rc) return rc;
+        a.w_lo = lo.d;
+        a.w_hi = hi.d;
+    }
+    launch_gp_terms(a, s);
+    launch_product_scan(num, n, 0, blk, npre, s);
+    launch_product_scan(den, n, 1, blk, dsuf, s);
+    HIPCHK(hipGetLastError());
+    Fr total;
+    HIPCHK(hipMemcpyAsync(&total, dsuf, sizeof(Fr), hipMemcpyDeviceToHost, s));  // S_0 = prod of all denominators
+    HIPCHK(hipStreamSynchronize(s));
+    launch_gp_finish(npre, dsuf, fe_inv(total), n, z_evals_out->d, s);
+    HIPCHK(hipGetLastError());
+    return TYPLONK_OK;
+}
+
+int typlonk_open_dev(typlonk_ctx* ctx, const typlonk_buf* poly, size_t offset, size_t m, const uint64_t z[4],
+                     typlonk_buf* q_out, uint64_t y_out[4]) {
+    if (!ctx || !poly || !z || !y_out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (m < 1) return fail(ctx, TYPLONK_ERR_LENGTH, "open needs at least 1 coefficient (kzg/src/lib.rs:58)");
+    if (m > (1u << 22)) return fail(ctx, TYPLONK_ERR_LENGTH, "open supports up to 2^22 coefficients");
+    if (offset > poly->n || m > poly->n - offset) return fail(ctx, TYPLONK_ERR_RANGE, "range outside buffer");
+    if (q_out && q_out->n < m - 1) return fail(ctx, TYPLONK_ERR_RANGE, "q_out shorter than m - 1");
+    if (q_out && q_out->d == poly->d) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "q_out must not alias poly");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->ops_tmp, (2048 + 8) * sizeof(Fr));
+    if (rc) return rc;
+    Fr* blocks = (Fr*)ctx->ops_tmp.p;
+    Fr* y_dev = blocks + 2048;
+    Fr zz;
+    memcpy(zz.v, z, 32);
+    launch_open(poly->d + offset, m, zz, q_out ? q_out->d : nullptr, blocks, y_dev, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(y_out, y_dev, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return TYPLONK_OK;
+}
+
+int typlonk_lincomb_dev(typlonk_ctx* ctx, const typlonk_buf* const* polys, const uint64_t (*scalars)[4], size_t terms,
+                        const uint64_t* constant, size_t n, typlonk_buf* out) {
+    if (!ctx || !out || (terms && (!polys || !scalars))) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (terms > 12) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "at most 12 terms");
+    if (out->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "out shorter than n");
+    HIPCHK(hipSetDevice(ctx->device));
+    LincombArgs a{};
+    for (size_t k = 0; k < terms; ++k) {
+        if (!polys[k] || polys[k]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "term shorter than n");
+        if (polys[k]->d == out->d) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "out must not alias a term");
+        a.poly[k] = polys[k]->d;
+        memcpy(a.scalar[k].v, scalars[k], 32);
+    }
+    a.constant = Fr::zero();
+    if (constant) memcpy(a.constant.v, constant, 32);
+    a.out = out->d;
+    a.n = n;
+    a.terms = (uint32_t)terms;
+    if (n) launch_lincomb(a, ctx->stream);
+    HIPCHK(hipGetLastError());
+    return TYPLONK_OK;
 }
 
 int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out) {

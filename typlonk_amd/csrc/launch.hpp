@@ -35,6 +35,35 @@ struct QuotientArgs {
 void launch_fr_fill(Fr* out, uint64_t n, const Fr& value, hipStream_t s);
 void launch_quotient_pointwise(const QuotientArgs& a, hipStream_t s);
 
+// grand product (plonk_ops.hip)
+struct GrandProductArgs {
+    const Fr* wires[3];   // witness column evaluations over the domain (n each)
+    const Fr* sigma[3];   // sigma evaluations (n each)
+    const Fr* w_lo;       // powers of w_n (two-level table)
+    const Fr* w_hi;
+    Fr* num;
+    Fr* den;
+    uint64_t n;
+    uint32_t w_h;
+    Fr beta, gamma;
+    Fr kbeta[3];          // k_i * beta
+};
+void launch_gp_terms(const GrandProductArgs& a, hipStream_t s);
+void launch_product_scan(const Fr* in, uint64_t n, int reverse, Fr* block_scratch, Fr* out, hipStream_t s);
+void launch_gp_finish(const Fr* nprefix, const Fr* dsuffix, const Fr& inv_total, uint64_t n, Fr* z, hipStream_t s);
+
+// open(): y = p(z) and q = (p - y)/(X - z) in one suffix scan; m <= 2^22 coefficients, q may be null
+void launch_open(const Fr* c, uint64_t m, const Fr& z, Fr* q, Fr* blocks, Fr* y, hipStream_t s);
+struct LincombArgs {
+    const Fr* poly[12];
+    Fr scalar[12];
+    Fr constant;
+    Fr* out;
+    uint64_t n;
+    uint32_t terms;
+};
+void launch_lincomb(const LincombArgs& a, hipStream_t s);
+
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s);
 
 void launch_convert_points(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);
