@@ -147,6 +147,31 @@ int typlonk_open_dev(typlonk_ctx* ctx, const typlonk_buf* poly, size_t offset, s
 int typlonk_lincomb_dev(typlonk_ctx* ctx, const typlonk_buf* const* polys, const uint64_t (*scalars)[4], size_t terms,
                         const uint64_t* constant, size_t n, typlonk_buf* out);
 
+/* ---- the prover's device-side flow: plonk::proof::prove (/root/reference/plonk/src/proof.rs:26-57, 96-194)
+ * split at its two Fiat-Shamir squeezes (challenges.rs is CPU-side and out of scope, so the caller
+ * supplies the challenges):
+ *   round1  columns (EVALUATIONS, n each, blinding rows included -- proof.rs:43-49) and the public-input
+ *           column -> a, b, c, PI by iNTT (:50, :105) and the commitments [a], [b], [c] (:107-110)
+ *   round2  beta, gamma (:111) -> grand product Z (:119), iNTT (:127), [Z] (:129)
+ *   round3  alpha, zeta (:133-136) -> quotient (:139), openings of a, b, c, Z at zeta and Z at zeta*w (:147-163),
+ *           linearisation polynomial r and its opening (:165-175), [t_lo], [t_mid], [t_hi] (:181)
+ * The circuit id comes from typlonk_circuit_load; the SRS must hold > n points.  n <= 2^22. */
+typedef struct typlonk_prover typlonk_prover;
+typedef struct typlonk_proof_tail {
+    uint64_t t_xy[3][12];   /* quotient slice commitments                                   */
+    uint8_t t_inf[3];
+    uint64_t w_xy[6][12];   /* opening witnesses: a, b, c at zeta; Z at zeta; Z at zeta*w; r at zeta */
+    uint8_t w_inf[6];
+    uint64_t evals[6][4];   /* a(zeta) b(zeta) c(zeta) Z(zeta) Z(zeta w) r(zeta)  (r(zeta) = 0 for a valid witness) */
+} typlonk_proof_tail;
+int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
+                          const typlonk_buf* pi_evals, typlonk_prover** out, uint64_t commit_xy[3][12],
+                          uint8_t commit_inf[3]);
+int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t cosets[3][4],
+                          uint64_t z_xy[12], uint8_t* z_inf);
+int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4], typlonk_proof_tail* out);
+void typlonk_prover_free(typlonk_prover* p);
+
 /* ---- device-resident Fr vectors (so an iNTT result feeds an MSM without crossing PCIe) ---------- */
 int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out);
 int typlonk_buf_free(typlonk_ctx* ctx, typlonk_buf* buf);

@@ -173,3 +173,75 @@ def prove_round_2_3(log_n, alpha, beta, gamma, x0=3, pi_evals=None):
     (t, rem), (line1, line4) = quotient_polynomial(log_n, wires, z, zw, q, sigma_polys, alpha, beta, gamma, pi)
     return {"n": n, "wires": wires, "z": z, "zw": zw, "q": q, "sigma": sigma_polys, "pi": pi, "t": t, "rem": rem,
             "line1": line1, "line4": line4, "cols": cols, "z_evals": evals}
+
+
+# ---- the whole prove(): rounds 1-5 with injected Fiat-Shamir challenges ------------------------------------
+def add_to_poly(p, x):
+    """plonk/src/utils.rs:13-20"""
+    if not p:
+        return trim([x % R])
+    q = list(p)
+    q[0] = (q[0] + x) % R
+    return trim(q)
+
+
+def linearisation_poly(log_n, q, sigma_polys, cosets, adv, z_eval_w, z, challenges, zeta, t_slices, public_eval):
+    """plonk/src/proof.rs:376-439.  adv = (a(zeta), b(zeta), c(zeta)); z_eval_w = Z(zeta w)."""
+    n = 1 << log_n
+    a, b, c = adv
+    alpha, beta, gamma = challenges
+    line1 = p_add(p_add(p_scale(q["q_l"], a), p_sub(p_scale(q["q_r"], b), p_scale(q["q_o"], c))),
+                  p_add(p_scale(q["q_m"], a * b % R), q["q_c"]))
+    line1 = add_to_poly(line1, public_eval)
+    l2 = 1
+    for k, e in zip(cosets, adv):
+        l2 = l2 * ((e + k * beta * zeta + gamma) % R) % R
+    line2 = p_scale(z, l2)
+    sig_ev = [O.poly_eval(s, zeta) for s in sigma_polys]
+    ab = (a + beta * sig_ev[0] + gamma) * (b + beta * sig_ev[1] + gamma) % R
+    cp_c = add_to_poly(p_scale(sigma_polys[2], beta), (gamma + c) % R)
+    line3 = p_scale(p_scale(cp_c, ab), z_eval_w)
+    copy_constrain = p_sub(line2, line3)
+    l0_eval = O.poly_eval(l0_poly(n), zeta)
+    line4 = p_scale(add_to_poly(z, R - 1), l0_eval)
+    compact = []
+    for idx, sl in enumerate(t_slices):                   # SlicedPoly::compact, degree = n
+        compact = p_add(compact, p_scale(sl, pow(zeta, n * idx, R)))
+    line5 = p_scale(compact, (pow(zeta, n, R) - 1) % R)   # evaluate_vanishing_polynomial
+    return p_sub(p_add(p_add(line1, p_scale(copy_constrain, alpha)), p_scale(line4, alpha * alpha % R)), line5)
+
+
+def prove(log_n, cols, q_evals, perm, pi_evals, challenges, zeta, commit):
+    """plonk/src/proof.rs:96-194.  `commit(coeffs)` is the KZG commitment function (an MSM against the
+    SRS).  Returns the proof elements in the order the reference produces them."""
+    n = 1 << log_n
+    alpha, beta, gamma = challenges
+    w = O.domain_root(log_n)
+    ids, sig = compile_permutation(perm, n, log_n)
+    wires = [O.interpolate(col, log_n) for col in cols]
+    pi = O.interpolate(pi_evals, log_n)
+    commitments = [commit(p) for p in wires]                                  # round1, :107-110
+    acc = grand_product(cols, ids, sig, beta, gamma, n)
+    evals = acc[:n]
+    z = O.interpolate(evals, log_n)
+    zw = O.interpolate(evals[1:] + evals[:1], log_n)
+    z_commit = commit(z)                                                      # :129
+    q = {k: O.interpolate(v, log_n) for k, v in q_evals.items()}
+    sigma_polys = [O.interpolate(s, log_n) for s in sig]
+    public_eval = O.poly_eval(pi, zeta)                                       # :138
+    (t, rem), _ = quotient_polynomial(log_n, wires, z, zw, q, sigma_polys, alpha, beta, gamma, pi)
+    t_slices = slices(t, n)
+
+    def open_(p, x):                                                          # kzg/src/lib.rs:55-64
+        qq, y = O.poly_div_linear(p, x)
+        return commit(qq), y
+
+    openings = [open_(p, zeta) for p in wires]                                # :147-154
+    adv = [o[1] for o in openings]
+    z_open = open_(z, zeta)                                                   # :162
+    zw_open = open_(z, zeta * w % R)                                          # :163
+    r = linearisation_poly(log_n, q, sigma_polys, COSETS, adv, zw_open[1], z, challenges, zeta, t_slices, public_eval)
+    r_open = open_(r, zeta)                                                   # :175
+    t_commit = [commit(s) for s in t_slices]                                  # :181
+    return {"commit": commitments, "open": openings, "z_commit": z_commit, "z_open": z_open, "zw_open": zw_open,
+            "t_commit": t_commit, "r_open": r_open, "r": r, "t": t, "rem": rem}

@@ -19,7 +19,8 @@ SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
-    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
+    "typlonk_prover_round3", "typlonk_prover_free", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
@@ -37,6 +38,12 @@ class QuotientArgs(C.Structure):
     _fields_ = [("wires", C.c_void_p * 3), ("z", C.c_void_p), ("selectors", C.c_void_p * 5), ("sigma", C.c_void_p * 3),
                 ("public_inputs", C.c_void_p), ("alpha", C.c_uint64 * 4), ("beta", C.c_uint64 * 4),
                 ("gamma", C.c_uint64 * 4), ("cosets", (C.c_uint64 * 4) * 3), ("circuit", C.c_uint32)]
+
+
+class ProofTail(C.Structure):
+    """typlonk_proof_tail"""
+    _fields_ = [("t_xy", (C.c_uint64 * 12) * 3), ("t_inf", C.c_uint8 * 3), ("w_xy", (C.c_uint64 * 12) * 6),
+                ("w_inf", C.c_uint8 * 6), ("evals", (C.c_uint64 * 4) * 6)]
 
 
 _lib = None
@@ -78,6 +85,12 @@ def load_library() -> C.CDLL:
                                               C.c_uint32, vp]
     lib.typlonk_open_dev.argtypes = [vp, vp, C.c_size_t, C.c_size_t, u64p, vp, u64p]
     lib.typlonk_lincomb_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64 * 4), C.c_size_t, u64p, C.c_size_t, vp]
+    lib.typlonk_prover_round1.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), vp, C.POINTER(vp),
+                                          C.POINTER((C.c_uint64 * 12) * 3), C.POINTER(C.c_uint8 * 3)]
+    lib.typlonk_prover_round2.argtypes = [vp, u64p, u64p, C.POINTER((C.c_uint64 * 4) * 3), u64p, u8p]
+    lib.typlonk_prover_round3.argtypes = [vp, u64p, u64p, C.POINTER(ProofTail)]
+    lib.typlonk_prover_free.argtypes = [vp]
+    lib.typlonk_prover_free.restype = None
     lib.typlonk_circuit_load.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.typlonk_circuit_free.argtypes = [vp, C.c_uint32]
     lib.typlonk_buf_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -322,6 +335,40 @@ class Context:
             cc = np.ascontiguousarray(constant, dtype=np.uint64).reshape(4)
             cp = _u64p(cc)
         self._chk(self.lib.typlonk_lincomb_dev(self.h, ptrs, sc, k, cp, n, out.handle))
+
+    def prove(self, sid: int, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34):
+        """Three-round prover session.  challenge12(commitments) -> (beta, gamma) and
+        challenge34(commitments + [Z]) -> (alpha, zeta) are callables returning 4-limb arrays (the
+        caller's Fiat-Shamir).  Returns a dict of numpy arrays in the C-ABI form."""
+        lib = self.lib
+        w = (C.c_void_p * 3)(*[b.handle.value for b in wire_evals])
+        pr = C.c_void_p()
+        cxy = ((C.c_uint64 * 12) * 3)()
+        cinf = (C.c_uint8 * 3)()
+        self._chk(lib.typlonk_prover_round1(self.h, sid, circuit, w, pi_evals.handle, C.byref(pr), C.byref(cxy),
+                                            C.byref(cinf)))
+        try:
+            commits = [(np.array(cxy[i], dtype=np.uint64), int(cinf[i])) for i in range(3)]
+            beta, gamma = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in challenge12(commits)]
+            ks = ((C.c_uint64 * 4) * 3)()
+            for i in range(3):
+                for j, limb in enumerate(np.asarray(cosets[i], dtype=np.uint64).reshape(4)):
+                    ks[i][j] = int(limb)
+            zxy = np.zeros(12, dtype=np.uint64)
+            zinf = np.zeros(1, dtype=np.uint8)
+            self._chk(lib.typlonk_prover_round2(pr, _u64p(beta), _u64p(gamma), C.byref(ks), _u64p(zxy), _u8p(zinf)))
+            alpha, zeta = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
+                           for x in challenge34(commits + [(zxy, int(zinf[0]))])]
+            tail = ProofTail()
+            self._chk(lib.typlonk_prover_round3(pr, _u64p(alpha), _u64p(zeta), C.byref(tail)))
+        finally:
+            lib.typlonk_prover_free(pr)
+        return {
+            "commit": commits, "z_commit": (zxy, int(zinf[0])),
+            "t_commit": [(np.array(tail.t_xy[i], dtype=np.uint64), int(tail.t_inf[i])) for i in range(3)],
+            "witness": [(np.array(tail.w_xy[i], dtype=np.uint64), int(tail.w_inf[i])) for i in range(6)],
+            "evals": [np.array(tail.evals[i], dtype=np.uint64) for i in range(6)],
+        }
 
     def circuit_load(self, log_n: int, selectors, sigma) -> int:
         sel = (C.c_void_p * 5)(*[b.handle.value for b in selectors])

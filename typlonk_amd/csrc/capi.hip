@@ -38,7 +38,9 @@ struct Table {
 // and L0 (9 vectors).  They are fixed per CompiledCircuit (plonk/src/lib.rs:19-35), so they are
 // transformed once instead of on every proof.
 struct CircuitEntry {
-    Fr* ext = nullptr;  // 9 * 4n
+    Fr* ext = nullptr;     // 9 * 4n : coset evaluations of q_l q_r q_o q_m q_c sigma_0..2 L0
+    Fr* coef = nullptr;    // 8 * n  : coefficient copies of the selectors and sigmas (linearisation, sigma(zeta))
+    Fr* sig_ev = nullptr;  // 3 * n  : sigma evaluations over the domain (grand product)
     uint32_t log_n = 0;
 };
 
@@ -674,7 +676,11 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     prof_begin(ctx);
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
-    for (auto& kv : ctx->circuits) (void)hipFree(kv.second.ext);
+    for (auto& kv : ctx->circuits) {
+        (void)hipFree(kv.second.ext);
+        (void)hipFree(kv.second.coef);
+        (void)hipFree(kv.second.sig_ev);
+    }
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
     for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->ops_tmp}) release(*b);
     for (MsmWs& ws : ctx->ws) {
@@ -892,12 +898,18 @@ int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5]
     CircuitEntry e;
     e.log_n = log_n;
     HIPCHK(hipMalloc((void**)&e.ext, 9 * n4 * sizeof(Fr)));
+    HIPCHK(hipMalloc((void**)&e.coef, 8 * n * sizeof(Fr)));
+    HIPCHK(hipMalloc((void**)&e.sig_ev, 3 * n * sizeof(Fr)));
+    for (int k = 0; k < 8; ++k)
+        HIPCHK(hipMemcpyAsync(e.coef + (uint64_t)k * n, in[k]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(e.sig_ev, e.coef + 5 * n, 3 * n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
     const bool prof = ctx->profiling;
     ctx->profiling = false;
     int rc = TYPLONK_OK;
     const Fr ninv = fe_inv(fr_from_u64(n));
     for (int k = 0; k < 9 && !rc; ++k)
         rc = quotient_extend(ctx, e.ext + (uint64_t)k * n4, k < 8 ? in[k]->d : nullptr, &ninv, n, log_n + 2);
+    for (int k = 0; k < 3 && !rc; ++k) rc = ntt_run(ctx, e.sig_ev + (uint64_t)k * n, log_n, 0, nullptr, /*sync=*/false);
     ctx->profiling = prof;
     if (!rc) {
         hipError_t he = hipStreamSynchronize(ctx->stream);
@@ -905,6 +917,8 @@ int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5]
     }
     if (rc) {
         (void)hipFree(e.ext);
+        (void)hipFree(e.coef);
+        (void)hipFree(e.sig_ev);
         return rc;
     }
     const uint32_t id = ctx->next_circuit++;
@@ -919,6 +933,8 @@ int typlonk_circuit_free(typlonk_ctx* ctx, uint32_t circuit_id) {
     if (it == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(it->second.ext));
+    HIPCHK(hipFree(it->second.coef));
+    HIPCHK(hipFree(it->second.sig_ev));
     ctx->circuits.erase(it);
     return TYPLONK_OK;
 }
@@ -1102,6 +1118,242 @@ int typlonk_lincomb_dev(typlonk_ctx* ctx, const typlonk_buf* const* polys, const
     if (n) launch_lincomb(a, ctx->stream);
     HIPCHK(hipGetLastError());
     return TYPLONK_OK;
+}
+
+// ================================================================================================
+// The prover's device-side flow: plonk::proof::prove (/root/reference/plonk/src/proof.rs:26-57, 96-194)
+// as three rounds around the two Fiat-Shamir squeezes.  Every polynomial stays in HBM from the
+// witness upload to the last commitment; the host only handles the few scalars of the linearisation.
+struct typlonk_prover {
+    typlonk_ctx* ctx = nullptr;
+    uint32_t srs_id = 0, circuit = 0, log_n = 0;
+    uint64_t n = 0;
+    Fr* mem = nullptr;  // one allocation, carved below
+    Fr *ev[3], *co[3], *pi, *z, *t, *q[6], *r;
+    Fr beta, gamma, k[3];
+    int round = 0;
+};
+
+namespace {
+int prover_commit_batch(typlonk_prover* p, const Fr* const* polys, const size_t* m, size_t count, uint64_t* xy, uint8_t* inf) {
+    std::vector<const void*> ptrs(count);
+    for (size_t i = 0; i < count; ++i) ptrs[i] = polys[i];
+    return msm_batch(p->ctx, p->srs_id, ptrs.data(), m, count, xy, inf);
+}
+int prover_open(typlonk_prover* p, const Fr* poly, uint64_t m, const Fr& z, Fr* q, Fr* y) {
+    typlonk_ctx* ctx = p->ctx;
+    int rc = ensure(ctx, ctx->ops_tmp, (2048 + 8) * sizeof(Fr));
+    if (rc) return rc;
+    Fr* blocks = (Fr*)ctx->ops_tmp.p;
+    launch_open(poly, m, z, q, blocks, blocks + 2048, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(y, blocks + 2048, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return TYPLONK_OK;
+}
+}  // namespace
+
+int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
+                          const typlonk_buf* pi_evals, typlonk_prover** out, uint64_t commit_xy[3][12],
+                          uint8_t commit_inf[3]) {
+    if (!ctx || !wire_evals || !pi_evals || !out || !commit_xy || !commit_inf)
+        return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto ci = ctx->circuits.find(circuit_id);
+    if (ci == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
+    const SrsEntry* srs = nullptr;
+    const uint32_t log_n = ci->second.log_n;
+    const uint64_t n = 1ull << log_n;
+    int rc = msm_validate(ctx, srs_id, n, &srs);  // every committed polynomial has <= n coefficients
+    if (rc) return rc;
+    if (n > (1u << 22)) return fail(ctx, TYPLONK_ERR_LENGTH, "prover supports up to 2^22 rows");
+    for (int i = 0; i < 3; ++i)
+        if (!wire_evals[i] || wire_evals[i]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "wire column shorter than n");
+    if (pi_evals->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "public-input column shorter than n");
+    typlonk_prover* p = new typlonk_prover();
+    p->ctx = ctx;
+    p->srs_id = srs_id;
+    p->circuit = circuit_id;
+    p->log_n = log_n;
+    p->n = n;
+    hipError_t he = hipMalloc((void**)&p->mem, (uint64_t)19 * n * sizeof(Fr));  // 3+3+1+1+4+6+1
+    if (he != hipSuccess) {
+        delete p;
+        return fail(ctx, TYPLONK_ERR_OOM, hipGetErrorString(he));
+    }
+    Fr* c = p->mem;
+    for (int i = 0; i < 3; ++i) { p->ev[i] = c; c += n; }
+    for (int i = 0; i < 3; ++i) { p->co[i] = c; c += n; }
+    p->pi = c; c += n;
+    p->z = c; c += n;
+    p->t = c; c += 4 * n;
+    for (int i = 0; i < 6; ++i) { p->q[i] = c; c += n; }
+    p->r = c;
+    hipStream_t s = ctx->stream;
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;
+    // a, b, c = interpolate(columns) (proof.rs:50); the column values themselves are kept for round 2
+    // (proof.rs:113-115 recomputes them with three forward FFTs)
+    for (int i = 0; i < 3 && !rc; ++i) {
+        hipMemcpyAsync(p->ev[i], wire_evals[i]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(p->co[i], wire_evals[i]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
+        rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false);
+    }
+    if (!rc) {
+        hipMemcpyAsync(p->pi, pi_evals->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
+        rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
+    }
+    if (!rc) {
+        const size_t m[3] = {n, n, n};
+        rc = prover_commit_batch(p, p->co, m, 3, &commit_xy[0][0], commit_inf);  // round1, proof.rs:107-110
+    }
+    ctx->profiling = prof;
+    if (rc) {
+        (void)hipFree(p->mem);
+        delete p;
+        return rc;
+    }
+    p->round = 1;
+    *out = p;
+    return TYPLONK_OK;
+}
+
+int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t cosets[3][4],
+                          uint64_t z_xy[12], uint8_t* z_inf) {
+    if (!p || !beta || !gamma || !cosets || !z_xy || !z_inf) return TYPLONK_ERR_INVALID_ARG;
+    typlonk_ctx* ctx = p->ctx;
+    if (p->round != 1) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round2 must follow round1");
+    HIPCHK(hipSetDevice(ctx->device));
+    const CircuitEntry& ce = ctx->circuits[p->circuit];
+    const uint64_t n = p->n;
+    memcpy(p->beta.v, beta, 32);
+    memcpy(p->gamma.v, gamma, 32);
+    for (int i = 0; i < 3; ++i) memcpy(p->k[i].v, cosets[i], 32);
+    typlonk_buf wb[3] = {{p->ev[0], n}, {p->ev[1], n}, {p->ev[2], n}};
+    typlonk_buf sb[3] = {{ce.sig_ev, n}, {ce.sig_ev + n, n}, {ce.sig_ev + 2 * n, n}};
+    const typlonk_buf* wp[3] = {&wb[0], &wb[1], &wb[2]};
+    const typlonk_buf* sp[3] = {&sb[0], &sb[1], &sb[2]};
+    typlonk_buf zb{p->z, n};
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;
+    int rc = typlonk_grand_product_dev(ctx, wp, sp, beta, gamma, cosets, p->log_n, &zb);  // proof.rs:119-120
+    if (!rc) rc = ntt_run(ctx, p->z, p->log_n, 1, nullptr, false);                          // :127-128
+    if (!rc) {
+        const Fr* polys[1] = {p->z};
+        const size_t m[1] = {n};
+        rc = prover_commit_batch(p, polys, m, 1, z_xy, z_inf);                              // :129
+    }
+    ctx->profiling = prof;
+    if (!rc) p->round = 2;
+    return rc;
+}
+
+int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4], typlonk_proof_tail* out) {
+    if (!p || !alpha || !zeta || !out) return TYPLONK_ERR_INVALID_ARG;
+    typlonk_ctx* ctx = p->ctx;
+    if (p->round != 2) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round3 must follow round2");
+    HIPCHK(hipSetDevice(ctx->device));
+    const CircuitEntry& ce = ctx->circuits[p->circuit];
+    const uint64_t n = p->n;
+    const uint32_t log_n = p->log_n;
+    Fr al, ze;
+    memcpy(al.v, alpha, 32);
+    memcpy(ze.v, zeta, 32);
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;
+    int rc;
+    // ---- quotient (proof.rs:139-145) ----
+    {
+        typlonk_buf b[5] = {{p->co[0], n}, {p->co[1], n}, {p->co[2], n}, {p->z, n}, {p->pi, n}};
+        typlonk_buf tb{p->t, 4 * n};
+        typlonk_quotient_args qa{};
+        for (int i = 0; i < 3; ++i) qa.wires[i] = &b[i];
+        qa.z = &b[3];
+        qa.public_inputs = &b[4];
+        memcpy(qa.alpha, alpha, 32);
+        memcpy(qa.beta, p->beta.v, 32);
+        memcpy(qa.gamma, p->gamma.v, 32);
+        for (int i = 0; i < 3; ++i) memcpy(qa.cosets[i], p->k[i].v, 32);
+        qa.circuit = p->circuit;
+        rc = typlonk_quotient_dev(ctx, &qa, log_n, &tb);
+    }
+    // ---- openings of a, b, c at zeta; Z at zeta and zeta*w (proof.rs:147-163) ----
+    Fr ev[6];
+    const Fr w = fr_domain_root(log_n);
+    const Fr zw = fe_mul(ze, w);
+    for (int i = 0; i < 3 && !rc; ++i) rc = prover_open(p, p->co[i], n, ze, p->q[i], &ev[i]);
+    if (!rc) rc = prover_open(p, p->z, n, ze, p->q[3], &ev[3]);
+    if (!rc) rc = prover_open(p, p->z, n, zw, p->q[4], &ev[4]);
+    // ---- linearisation polynomial (proof.rs:376-439) ----
+    Fr s0, s1, pi_z;
+    if (!rc) rc = prover_open(p, ce.coef + 5 * n, n, ze, nullptr, &s0);   // sigma_0(zeta)
+    if (!rc) rc = prover_open(p, ce.coef + 6 * n, n, ze, nullptr, &s1);   // sigma_1(zeta)
+    if (!rc) rc = prover_open(p, p->pi, n, ze, nullptr, &pi_z);           // public_eval, proof.rs:138
+    if (!rc) {
+        const Fr one = Fr::one();
+        Fr zn = ze;  // zeta^n
+        for (uint32_t i = 0; i < log_n; ++i) zn = fe_sqr(zn);
+        const Fr zh = fe_sub(zn, one);  // evaluate_vanishing_polynomial(zeta)
+        // L0(zeta) = (zeta^n - 1) / (n (zeta - 1)); the polynomial (1/n) sum X^i evaluates to 1 at zeta = 1
+        Fr l0z = one;
+        const Fr zm1 = fe_sub(ze, one);
+        if (!zm1.is_zero()) l0z = fe_mul(zh, fe_inv(fe_mul(fr_from_u64(n), zm1)));
+        const Fr &a = ev[0], &b = ev[1], &c = ev[2], &zwe = ev[4];
+        const Fr &beta = p->beta, &gamma = p->gamma;
+        const Fr bz = fe_mul(beta, ze);
+        Fr l2 = one;  // prod_i (w_i(zeta) + k_i beta zeta + gamma)
+        for (int i = 0; i < 3; ++i) l2 = fe_mul(l2, fe_add(fe_add(ev[i], fe_mul(p->k[i], bz)), gamma));
+        const Fr ab = fe_mul(fe_add(fe_add(a, fe_mul(beta, s0)), gamma), fe_add(fe_add(b, fe_mul(beta, s1)), gamma));
+        const Fr abz = fe_mul(ab, zwe);          // copy_permutation_ab * Z(zeta w)
+        const Fr al2 = fe_sqr(al);
+        LincombArgs la{};
+        int k = 0;
+        auto term = [&](const Fr* poly, const Fr& sc) { la.poly[k] = poly; la.scalar[k] = sc; ++k; };
+        term(ce.coef + 0 * n, a);                                   // q_l a
+        term(ce.coef + 1 * n, b);                                   // q_r b
+        term(ce.coef + 2 * n, fe_neg(c));                           // - q_o c
+        term(ce.coef + 3 * n, fe_mul(a, b));                        // q_m a b
+        term(ce.coef + 4 * n, one);                                 // q_c
+        term(p->z, fe_add(fe_mul(al, l2), fe_mul(al2, l0z)));       // Z (alpha line2 + alpha^2 L0)
+        term(ce.coef + 7 * n, fe_neg(fe_mul(al, fe_mul(beta, abz))));  // - alpha beta sigma_2 AB Z(zw)
+        term(p->t, fe_neg(zh));                                     // - Z_H t_lo
+        term(p->t + n, fe_neg(fe_mul(zh, zn)));                     // - Z_H zeta^n t_mid
+        term(p->t + 2 * n, fe_neg(fe_mul(zh, fe_sqr(zn))));         // - Z_H zeta^2n t_hi
+        la.terms = (uint32_t)k;
+        // constant: PI(zeta) - alpha (gamma + c) AB Z(zw) - alpha^2 L0
+        la.constant = fe_sub(fe_sub(pi_z, fe_mul(al, fe_mul(fe_add(gamma, c), abz))), fe_mul(al2, l0z));
+        la.out = p->r;
+        la.n = n;
+        launch_lincomb(la, ctx->stream);
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
+    }
+    if (!rc) rc = prover_open(p, p->r, n, ze, p->q[5], &ev[5]);          // proof.rs:175
+    // ---- the nine remaining commitments in one batch: 6 opening witnesses + 3 quotient slices (:181) ----
+    if (!rc) {
+        const Fr* polys[9] = {p->q[0], p->q[1], p->q[2], p->q[3], p->q[4], p->q[5], p->t, p->t + n, p->t + 2 * n};
+        const size_t m[9] = {n - 1, n - 1, n - 1, n - 1, n - 1, n - 1, n, n, n > 3 ? n - 3 : 0};
+        uint64_t xy[9][12];
+        uint8_t inf[9];
+        rc = prover_commit_batch(p, polys, m, 9, &xy[0][0], inf);
+        if (!rc) {
+            memcpy(out->w_xy, xy, 6 * 96);
+            memcpy(out->w_inf, inf, 6);
+            memcpy(out->t_xy, xy[6], 3 * 96);
+            memcpy(out->t_inf, inf + 6, 3);
+            for (int i = 0; i < 6; ++i) memcpy(out->evals[i], ev[i].v, 32);
+        }
+    }
+    ctx->profiling = prof;
+    if (!rc) p->round = 3;
+    return rc;
+}
+
+void typlonk_prover_free(typlonk_prover* p) {
+    if (!p) return;
+    (void)hipStreamSynchronize(p->ctx->stream);
+    (void)hipFree(p->mem);
+    delete p;
 }
 
 int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out) {
