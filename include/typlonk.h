@@ -62,6 +62,12 @@ int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, s
 int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t start, size_t len, uint32_t* srs_id);
 /* Copy `count` points starting at `offset` back to the host (xy: count*12 limbs; inf: count or NULL). */
 int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_t count, uint64_t* xy, uint8_t* inf);
+/* Optional fixed-base precomputation (the SRS is immutable per circuit, plonk/src/lib.rs:22): builds the
+ * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM, c = window_bits in
+ * 16..20; 20 is the balanced choice: its top window still has 15 bits).  Later MSMs of at least len/4
+ * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
+ * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point. */
+int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bits);
 int typlonk_srs_free(typlonk_ctx* ctx, uint32_t srs_id);
 int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
 

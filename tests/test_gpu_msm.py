@@ -263,3 +263,64 @@ def test_adversarial_scalars_at_2_16_use_heavy_bucket_tasks(ctx, name):
     assert (out == exp).all() and inf == einf
     assert dt < 5.0, f"adversarial MSM took {dt:.1f} s"
     ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("c", [16, 17, 18, 19, 20])
+def test_fixed_base_tables_give_identical_results(ctx, c):
+    """typlonk_srs_precompute: the table-mode MSM (shared bucket set, no window recombination) returns
+    exactly the same points as the plain path, for full and shorter lengths, incl. adversarial sets"""
+    from oracle import coracle as CO
+
+    n = 1 << 13
+    s_limbs = np.array(O.fr_to_mont_limbs(0x0123456789ABCDEF0123456789ABCDEF), dtype=np.uint64)
+    sid_plain = ctx.srs_generate(s_limbs, n + 3)
+    sid_tab = ctx.srs_generate(s_limbs, n + 3)
+    ctx.srs_precompute(sid_tab, c)
+    xy, inf = ctx.srs_download(sid_tab)                 # table 0 is still the SRS itself
+    xy0, inf0 = ctx.srs_download(sid_plain)
+    assert (xy == xy0).all() and (inf == inf0).all()
+    rng = np.random.default_rng(c)
+    for m in (n, n - 1, n - 3, n // 2 + 5, 100):        # 100 < len/4 falls back to the plain path on table 0
+        sc = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(m, 4), dtype=np.uint64)
+        sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+        a, ai = ctx.msm(sid_plain, sc)
+        b, bi = ctx.msm(sid_tab, sc)
+        assert (a == b).all() and ai == bi
+    one = np.tile(np.array(O.fr_to_mont_limbs(1), dtype=np.uint64), (n, 1))
+    rm1 = np.tile(np.array(O.fr_to_mont_limbs(O.R - 1), dtype=np.uint64), (n, 1))
+    for sc in (one, rm1, np.zeros((n, 4), dtype=np.uint64)):
+        a, ai = ctx.msm(sid_plain, sc)
+        b, bi = ctx.msm(sid_tab, sc)
+        assert (a == b).all() and ai == bi
+    # against the oracle once (reference-faithful per-term MSM on a slice)
+    sc = rng.integers(0, 1 << 62, size=(2048, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    sid_small = ctx.srs_generate(s_limbs, 2048)
+    ctx.srs_precompute(sid_small, c)
+    b, bi = ctx.msm(sid_small, sc)
+    r, ri = CO.msm_reference(sc, xy[:2048], inf[:2048])
+    assert (b == r).all() and bi == ri
+    for sid in (sid_plain, sid_tab, sid_small):
+        ctx.srs_free(sid)
+
+
+def test_fixed_base_tables_commit_identity_2_18(ctx):
+    """table mode (c = 20, the shape bench.py uses) at 2^18 terms: commit(p) == [p(s)]G, plus the batch
+    entry point and the n-1 / n-3 lengths of prove()"""
+    from oracle import coracle as CO
+
+    n = 1 << 18
+    s_limbs = np.array(O.fr_to_mont_limbs(2), dtype=np.uint64)
+    sid = ctx.srs_generate(s_limbs, n + 3)
+    ctx.srs_precompute(sid, 20)
+    rng = np.random.default_rng(2018)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    buf = ctx.alloc(n)
+    buf.upload(sc)
+    res = ctx.msm_batch_devptr(sid, [buf.devptr] * 3, [n, n - 1, n - 3])
+    for (out, inf), m in zip(res, (n, n - 1, n - 3)):
+        exp, einf = CO.g1_mul_generator(CO.poly_eval(sc[:m], s_limbs))
+        assert (out == exp).all() and inf == einf
+    buf.free()
+    ctx.srs_free(sid)

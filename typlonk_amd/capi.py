@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RA
 # every symbol include/typlonk.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
-    "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
+    "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_precompute", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
     "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
     "typlonk_prover_round3", "typlonk_prover_free", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
@@ -71,6 +71,7 @@ def load_library() -> C.CDLL:
     lib.typlonk_srs_load.argtypes = [vp, u64p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
     lib.typlonk_srs_generate.argtypes = [vp, u64p, C.c_uint64, C.c_size_t, C.POINTER(C.c_uint32)]
     lib.typlonk_srs_download.argtypes = [vp, C.c_uint32, C.c_size_t, C.c_size_t, u64p, u8p]
+    lib.typlonk_srs_precompute.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.typlonk_srs_free.argtypes = [vp, C.c_uint32]
     lib.typlonk_srs_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
     lib.typlonk_msm_g1.argtypes = [vp, C.c_uint32, u64p, C.c_size_t, u64p, u8p]
@@ -233,6 +234,10 @@ class Context:
         inf = np.zeros(count, dtype=np.uint8)
         self._chk(self.lib.typlonk_srs_download(self.h, sid, offset, count, _u64p(xy), _u8p(inf)))
         return xy, inf
+
+    def srs_precompute(self, sid: int, window_bits: int = 18):
+        """fixed-base window tables for this SRS (typlonk_srs_precompute)"""
+        self._chk(self.lib.typlonk_srs_precompute(self.h, sid, window_bits))
 
     def srs_free(self, sid: int):
         self._chk(self.lib.typlonk_srs_free(self.h, sid))

@@ -27,6 +27,7 @@ struct DevBuf {
 struct SrsEntry {
     uint32_t* d_points = nullptr;  // len * PT_WORDS u32 (96 B payload on a 128-B stride), identity = (0,0)
     size_t len = 0;
+    uint32_t table_c = 0, table_T = 0;  // fixed-base tables 2^(c t) P_i at index t*len + i (typlonk_srs_precompute)
 };
 
 struct Table {
@@ -87,7 +88,8 @@ struct typlonk_ctx {
     hipStream_t stream2 = nullptr;  // second lane of typlonk_msm_g1_batch*
     hipEvent_t batch_evt = nullptr;
     // NTT
-    DevBuf ntt_scratch, ntt_io, quot_ext, ops_tmp;
+    DevBuf ntt_scratch, ntt_io, quot_ext, ops_tmp, prover_mem;
+    bool prover_busy = false;  // one proof in flight per context (the arena above is shared)
     std::map<std::string, Table> tables;
     // profiling
     bool profiling = false;
@@ -433,16 +435,29 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     if (!ws.host_wins) HIPCHK(hipHostMalloc((void**)&ws.host_wins, 64 * 192));
     uint32_t c, W;
     msm_shape(ctx, m, &c, &W);
+    // fixed-base tables: every window reads its own pre-shifted copy of the base, so all windows share
+    // one bucket set (plus a separate set for a thin top window) and no cross-window doublings remain
+    const bool tables = srs.table_T != 0 && m >= srs.len / 4 && srs.len <= (1u << 23) && !ctx->msm_legacy_sort;
+    if (tables) {
+        c = srs.table_c;
+        W = srs.table_T;
+    }
     const uint32_t B = 1u << (c - 1);
     // top window: t scalar bits -> 2^t digits, spread over 2^top_v virtual bucket copies
     const uint32_t t_bits = 255 - c * (W - 1);
     const uint32_t top_v = (t_bits >= c - 1) ? 0u : (c - 1 - t_bits);
-    const uint64_t nb = (uint64_t)W * B;
+    // table mode: ONE bucket set for all windows -- the top window's digits d <= 2^t go to the shared
+    // buckets d - 1 with their true weight (no virtual copies).  Balanced when t is large (c = 20: t = 15);
+    // for a thin top window the heavy-bucket tasks keep it correct, just slower.
+    const uint32_t nsets = tables ? 1u : W;
+    const uint32_t digit_v = tables ? 0u : top_v;
+    const uint64_t nb = (uint64_t)nsets * B;
+    const uint64_t nb_used = nb;
     const uint64_t total = (uint64_t)W * m;
     if (total >= (1ull << 31)) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM too large for 32-bit entry indices");
     const uint32_t L = std::min<uint32_t>(MSM_SEG, B);
     const uint32_t npw = B / L;
-    const uint32_t nodes = W * npw;
+    const uint32_t nodes = nsets * npw;
     const uint32_t scan_blocks = (uint32_t)((nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
 
     int rc;
@@ -456,7 +471,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     if ((rc = ensure(ctx, ws.order, nb * 4))) return rc;
     if ((rc = ensure(ctx, ws.ohist, 514 * 4))) return rc;
     // heavy-bucket splitting: cap = entries one thread may sum; at most total/cap heavy buckets/tasks
-    const uint32_t cap = (uint32_t)std::max<uint64_t>(512, 4 * ((total + nb - 1) / nb));
+    const uint32_t cap = (uint32_t)std::max<uint64_t>(512, 4 * ((total + nb_used - 1) / nb_used));
     const uint64_t max_tasks = total / cap + 2;
     if ((rc = ensure(ctx, ws.heavy, max_tasks * 12))) return rc;
     if ((rc = ensure(ctx, ws.tasks, max_tasks * 8))) return rc;
@@ -475,23 +490,29 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     uint32_t* pb = (uint32_t*)ws.part_b.p;
     hipStream_t s = ws.stream;
 
-    // segmented sort shape: hb high bucket bits pick the segment, lb <= 8 low bits are sorted in LDS
+    // segmented sort shape: hb high bucket bits pick the segment, lb <= 8 low bits are sorted in LDS;
+    // the level-1 entry packs [i : ibits][j : 4 in table mode][sign][low : lb] into 32 bits
     uint32_t lgm = 0;
     while (((uint64_t)1 << lgm) < m) ++lgm;
-    int hb = std::max<int>((int)c - 9, (int)lgm - 13);
+    const uint32_t ibits = tables ? std::max<uint32_t>(lgm, 1) : 23;
+    const int lb_max = tables ? std::min<int>(8, 32 - (int)ibits - 5) : 8;
+    int hb = std::max<int>((int)c - 1 - lb_max, tables ? 0 : (int)lgm - 13);
     hb = std::max(0, std::min<int>(hb, (int)c - 1));
-    const uint64_t nseg = (uint64_t)W << hb;
+    const uint64_t nseg = (uint64_t)nsets << hb;
     const uint64_t nblk = (m + 2047) / 2048;
     const uint64_t nmat = nseg * nblk;
-    const bool segsort = !ctx->msm_legacy_sort && m <= (1u << 23) && nseg * 4 <= 64 * 1024 && nmat < (1ull << 31);
+    const bool segsort = !ctx->msm_legacy_sort && m <= (1u << 23) && nseg * 4 <= 64 * 1024 && nmat < (1ull << 31) &&
+                         (!tables || W <= 16);
+    if (tables && !segsort) return fail(ctx, TYPLONK_ERR_LENGTH, "table-mode MSM shape not supported");
     if (segsort) {
         if ((rc = ensure(ctx, ws.blk_hist, nmat * 4))) return rc;
         if ((rc = ensure(ctx, ws.blk_base, (nmat + 1) * 4))) return rc;
         if ((rc = ensure(ctx, ws.blocksums, (size_t)((nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks) * 4))) return rc;
         blocksums = (uint32_t*)ws.blocksums.p;
         StageTimer st(ctx, "msm_sort", s);
-        launch_msm_segsort(d_scalars, (uint64_t)m, c, W, top_v, (uint32_t)hb, (uint32_t*)ws.blk_hist.p,
-                           (uint32_t*)ws.blk_base.p, blocksums, keys, counts, offsets, sorted, s);
+        launch_msm_segsort(d_scalars, (uint64_t)m, c, W, digit_v, (uint32_t)hb, ibits, tables ? (uint32_t)srs.len : 0u,
+                           tables ? nsets : 0u, (uint32_t*)ws.blk_hist.p, (uint32_t*)ws.blk_base.p, blocksums, keys,
+                           counts, offsets, sorted, s);
     } else {
         {
             StageTimer st(ctx, "msm_digits", s);
@@ -509,36 +530,43 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     }
     {
         StageTimer st(ctx, "msm_order", s);
-        launch_bucket_order(counts, offsets, (uint32_t)nb, cap, (uint32_t*)ws.ohist.p, (uint32_t*)ws.order.p,
+        launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)ws.ohist.p, (uint32_t*)ws.order.p,
                             (uint32_t*)ws.heavy.p, (uint32_t*)ws.tasks.p, s);
     }
     {
         StageTimer st(ctx, "msm_accum", s);
-        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ws.order.p, (uint32_t)nb, cap, buckets, s);
+        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ws.order.p, (uint32_t)nb_used, cap, buckets, s);
         launch_msm_heavy(srs.d_points, sorted, (const uint32_t*)ws.ohist.p, (const uint32_t*)ws.heavy.p,
                          (const uint32_t*)ws.tasks.p, (uint32_t*)ws.hpart.p, buckets, s);
     }
-    uint32_t* cur = pa;
-    uint32_t* other = pb;
-    uint32_t n_in;
-    {
-        StageTimer st(ctx, "msm_reduce", s);
-        const uint32_t group = std::min<uint32_t>(64, npw);
-        launch_msm_reduce(buckets, B, L, nodes, group, c, W, top_v, cur, s);
-        n_in = npw / group;
+    // reduce one group of `nwin` equally sized windows of `Bw` buckets starting at bucket `first`; the
+    // window sums land in ws.host_wins[slot ...]
+    auto reduce_group = [&](uint64_t first, uint32_t Bw, uint32_t nwin, uint32_t v_last, uint32_t slot) -> int {
+        const uint32_t Lw = std::min<uint32_t>(MSM_SEG, Bw);
+        const uint32_t npw_w = Bw / Lw;
+        const uint32_t nodes_w = nwin * npw_w;
+        uint32_t* cur = pa;
+        uint32_t* other = pb;
+        const uint32_t group = std::min<uint32_t>(64, npw_w);
+        launch_msm_reduce(buckets + first * 48, Bw, Lw, nodes_w, group, c, nwin, v_last, cur, s);
+        uint32_t n_in = npw_w / group;
         while (n_in > 1) {
             const uint32_t g2 = std::min<uint32_t>(64, n_in);
-            const uint32_t tot = W * n_in;
-            launch_msm_fold(cur, tot, g2, other, s);
+            launch_msm_fold(cur, nwin * n_in, g2, other, s);
             std::swap(cur, other);
             n_in /= g2;
         }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ws.host_wins + (size_t)slot * 48, cur, (size_t)nwin * 192, hipMemcpyDeviceToHost, s));
+        return TYPLONK_OK;
+    };
+    {
+        StageTimer st(ctx, "msm_reduce", s);
+        if ((rc = reduce_group(0, B, nsets, digit_v, 0))) return rc;
     }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ws.host_wins, cur, (size_t)W * 192, hipMemcpyDeviceToHost, s));
     ws.pending = true;
-    ws.W = W;
-    ws.c = c;
+    ws.W = nsets;
+    ws.c = tables ? 0 : c;  // table mode: the set sums are simply added
     ws.out_xy = out_xy;
     ws.out_inf = out_inf;
     return TYPLONK_OK;
@@ -682,7 +710,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
         (void)hipFree(kv.second.sig_ev);
     }
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
-    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->ops_tmp}) release(*b);
+    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (DevBuf* b : {&ws.keys, &ws.sorted, &ws.counts, &ws.offsets, &ws.cursor, &ws.blocksums, &ws.buckets, &ws.part_a,
                           &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base, &ws.heavy, &ws.tasks, &ws.hpart})
@@ -766,6 +794,29 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
     const uint32_t id = ctx->next_srs++;
     ctx->srs[id] = e;
     *srs_id = id;
+    return TYPLONK_OK;
+}
+
+int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bits) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    if (window_bits < 16 || window_bits > 20) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "window_bits must be 16..20");
+    SrsEntry& e = it->second;
+    if (e.table_T) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "tables already built for this SRS");
+    if (e.len == 0 || e.len > (1u << 23)) return fail(ctx, TYPLONK_ERR_LENGTH, "tables need 1 <= len <= 2^23");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t T = (256 + window_bits - 1) / window_bits;
+    uint32_t* big = nullptr;
+    HIPCHK(hipMalloc((void**)&big, (size_t)T * e.len * PT_WORDS * 4));
+    HIPCHK(hipMemcpyAsync(big, e.d_points, e.len * PT_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    launch_srs_tables(big, (uint64_t)e.len, window_bits, T, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(e.d_points));
+    e.d_points = big;
+    e.table_c = window_bits;
+    e.table_T = T;
     return TYPLONK_OK;
 }
 
@@ -1170,17 +1221,16 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     for (int i = 0; i < 3; ++i)
         if (!wire_evals[i] || wire_evals[i]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "wire column shorter than n");
     if (pi_evals->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "public-input column shorter than n");
+    if (ctx->prover_busy) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "a proof is already in flight on this context");
+    rc = ensure(ctx, ctx->prover_mem, (uint64_t)19 * n * sizeof(Fr));  // 3+3+1+1+4+6+1 vectors, kept across proofs
+    if (rc) return rc;
     typlonk_prover* p = new typlonk_prover();
     p->ctx = ctx;
     p->srs_id = srs_id;
     p->circuit = circuit_id;
     p->log_n = log_n;
     p->n = n;
-    hipError_t he = hipMalloc((void**)&p->mem, (uint64_t)19 * n * sizeof(Fr));  // 3+3+1+1+4+6+1
-    if (he != hipSuccess) {
-        delete p;
-        return fail(ctx, TYPLONK_ERR_OOM, hipGetErrorString(he));
-    }
+    p->mem = (Fr*)ctx->prover_mem.p;
     Fr* c = p->mem;
     for (int i = 0; i < 3; ++i) { p->ev[i] = c; c += n; }
     for (int i = 0; i < 3; ++i) { p->co[i] = c; c += n; }
@@ -1209,11 +1259,11 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     }
     ctx->profiling = prof;
     if (rc) {
-        (void)hipFree(p->mem);
         delete p;
         return rc;
     }
     p->round = 1;
+    ctx->prover_busy = true;
     *out = p;
     return TYPLONK_OK;
 }
@@ -1224,7 +1274,9 @@ int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint6
     typlonk_ctx* ctx = p->ctx;
     if (p->round != 1) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round2 must follow round1");
     HIPCHK(hipSetDevice(ctx->device));
-    const CircuitEntry& ce = ctx->circuits[p->circuit];
+    auto cit = ctx->circuits.find(p->circuit);
+    if (cit == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "circuit was freed during the proof");
+    const CircuitEntry& ce = cit->second;
     const uint64_t n = p->n;
     memcpy(p->beta.v, beta, 32);
     memcpy(p->gamma.v, gamma, 32);
@@ -1253,7 +1305,9 @@ int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint
     typlonk_ctx* ctx = p->ctx;
     if (p->round != 2) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round3 must follow round2");
     HIPCHK(hipSetDevice(ctx->device));
-    const CircuitEntry& ce = ctx->circuits[p->circuit];
+    auto cit = ctx->circuits.find(p->circuit);
+    if (cit == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "circuit was freed during the proof");
+    const CircuitEntry& ce = cit->second;
     const uint64_t n = p->n;
     const uint32_t log_n = p->log_n;
     Fr al, ze;
@@ -1352,7 +1406,7 @@ int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint
 void typlonk_prover_free(typlonk_prover* p) {
     if (!p) return;
     (void)hipStreamSynchronize(p->ctx->stream);
-    (void)hipFree(p->mem);
+    p->ctx->prover_busy = false;
     delete p;
 }
 

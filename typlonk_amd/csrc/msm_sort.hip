@@ -161,7 +161,17 @@ constexpr int MSM_CHUNK = 2048;  // scalars per workgroup = 8 per thread
 
 struct MsmShape {
     uint32_t c, W, top_v, hb, lb, nseg, nblk;
+    // level-1 entry layout: [i : ibits][j : jbits][sign : 1][low bucket bits : lb]
+    uint32_t ibits, jbits;
+    // fixed-base table mode (tlen != 0): base (j, i) lives at gather index j * tlen + i and all windows
+    // share one bucket set (nsets = 1)
+    uint32_t tlen, nsets;
 };
+
+__device__ __forceinline__ uint32_t msm_seg_of(const MsmShape& sh, uint32_t j, uint32_t b) {
+    if (sh.tlen) return b >> sh.lb;
+    return (j << sh.hb) | (b >> sh.lb);
+}
 
 // canonical scalar -> (bucket-in-window, sign) for every window, in window order
 template <class F>
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256) void msm_seg_hist_kernel(const Fr* scalars, ui
             uint32_t v[8];
             msm_load_canon(scalars, i, v);
             msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t) {
-                atomicAdd(&seg_h[(j << sh.hb) | (b >> sh.lb)], 1u);
+                atomicAdd(&seg_h[msm_seg_of(sh, j, b)], 1u);
             });
         }
     }
@@ -230,8 +240,9 @@ __global__ __launch_bounds__(256) void msm_seg_scatter_kernel(const Fr* scalars,
             uint32_t v[8];
             msm_load_canon(scalars, i, v);
             msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
-                const uint32_t pos = atomicAdd(&cur[(j << sh.hb) | (b >> sh.lb)], 1u);
-                entries[pos] = (uint32_t)i | (neg << 23) | ((b & lmask) << 24);
+                const uint32_t pos = atomicAdd(&cur[msm_seg_of(sh, j, b)], 1u);
+                entries[pos] = (uint32_t)i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
+                               ((b & lmask) << (sh.ibits + sh.jbits + 1));
             });
         }
     }
@@ -251,7 +262,8 @@ __global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __res
     const uint32_t end = (s + 1 < sh.nseg) ? blk_base[(uint64_t)(s + 1) * sh.nblk] : blk_base[total_slot];
     hist[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t e = start + threadIdx.x; e < end; e += 256) atomicAdd(&hist[entries[e] >> 24], 1u);
+    const uint32_t low_sh = sh.ibits + sh.jbits + 1;
+    for (uint32_t e = start + threadIdx.x; e < end; e += 256) atomicAdd(&hist[entries[e] >> low_sh], 1u);
     __syncthreads();
     const uint32_t mine = hist[threadIdx.x];
     pref[threadIdx.x] = mine;
@@ -276,9 +288,12 @@ __global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __res
     __syncthreads();
     for (uint32_t e = start + threadIdx.x; e < end; e += 256) {
         const uint32_t v = entries[e];
-        const uint32_t b = v >> 24;
+        const uint32_t b = v >> low_sh;
         const uint32_t r = atomicAdd(&hist[b], 1u);
-        sorted[start + pref[b] + r] = (v & 0x7fffffu) | ((v & 0x800000u) << 8);
+        const uint32_t i = v & ((1u << sh.ibits) - 1);
+        const uint32_t j = (v >> sh.ibits) & ((1u << sh.jbits) - 1);
+        const uint32_t neg = (v >> (sh.ibits + sh.jbits)) & 1u;
+        sorted[start + pref[b] + r] = (j * sh.tlen + i) | (neg << 31);
     }
 }
 
@@ -389,15 +404,20 @@ void launch_exclusive_scan(const uint32_t* in, uint64_t n, uint32_t* block_sums,
 }
 
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
-                        uint32_t* blk_hist, uint32_t* blk_base, uint32_t* scan_scratch, uint32_t* entries,
-                        uint32_t* counts, uint32_t* offsets, uint32_t* sorted, hipStream_t s) {
+                        uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
+                        uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
+                        hipStream_t s) {
     MsmShape sh;
     sh.c = c;
     sh.W = W;
     sh.top_v = top_v;
     sh.hb = hb;
     sh.lb = c - 1 - hb;
-    sh.nseg = W << hb;
+    sh.ibits = ibits;
+    sh.jbits = tlen ? 4 : 0;
+    sh.tlen = tlen;
+    sh.nsets = nsets;
+    sh.nseg = (tlen ? nsets : W) << hb;
     sh.nblk = (uint32_t)((m + MSM_CHUNK - 1) / MSM_CHUNK);
     const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
     hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(256), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,

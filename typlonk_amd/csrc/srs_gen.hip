@@ -38,6 +38,29 @@ __global__ __launch_bounds__(64) void srs_generate_kernel(SrsGenArgs a) {
     st_fq(p + 12, r.y);
 }
 
+// Fixed-base window tables: table t holds 2^(c*t) * P_i (affine, canonical) at point index t*len + i,
+// table 0 being the SRS itself.  One thread per base walks the tables: c doublings, one inversion.
+// Setup-time only; it trades HBM capacity (T x the SRS) for the whole cross-window recombination of
+// every later MSM over this SRS.
+__global__ __launch_bounds__(64) void srs_tables_kernel(uint32_t* pts, uint64_t len, uint32_t c, uint32_t T) {
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= len) return;
+    G1Affine p = ld_affine(pts, i);
+    for (uint32_t t = 1; t < T; ++t) {
+        uint32_t* dst = pts + (t * len + i) * PT_WORDS;
+        if (!p.is_inf()) {
+            G1Xyzz acc = G1Xyzz::from_affine(p);
+            for (uint32_t d = 0; d < c; ++d) acc = g1_dbl(acc);
+            p = g1_to_affine(acc);
+        }
+        st_fq(dst, p.x);
+        st_fq(dst + 12, p.y);
+    }
+}
+void launch_srs_tables(uint32_t* pts, uint64_t len, uint32_t c, uint32_t T, hipStream_t s) {
+    hipLaunchKernelGGL(srs_tables_kernel, dim3((unsigned)((len + 63) / 64)), dim3(64), 0, s, pts, len, c, T);
+}
+
 void launch_srs_generate(const Fr& s, uint64_t start, uint64_t n, uint32_t* pts, hipStream_t st) {
     SrsGenArgs a;
     a.s = s;
