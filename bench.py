@@ -75,7 +75,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 13, help="terms of the workload timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 16,
+                    help="terms of the workload timed on the CPU oracle (2^16 ~ 16 s on one host core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tables", type=int, default=20,
                     help="window bits of the fixed-base tables built once per SRS shard (0 = none); used when the "
