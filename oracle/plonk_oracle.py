@@ -245,3 +245,27 @@ def prove(log_n, cols, q_evals, perm, pi_evals, challenges, zeta, commit):
     t_commit = [commit(s) for s in t_slices]                                  # :181
     return {"commit": commitments, "open": openings, "z_commit": z_commit, "z_open": z_open, "zw_open": zw_open,
             "t_commit": t_commit, "r_open": r_open, "r": r, "t": t, "rem": rem}
+
+
+# ---- the README circuit (a*a + b*b == c*c), SURVEY.md KAT-5 --------------------------------------------
+def pythagorean_circuit(inputs, blinders=None):
+    """README.md:16-27 / plonk/src/builder/test.rs:25-37: gates Mul, Mul, Mul, Add -> n = 8 rows.
+    Returns (log_n, cols, q_evals, perm) exactly as CircuitBuilder::compile + ComputeVar produce them
+    (witness columns before blinding a=[x,y,z,x^2,0] b=[x,y,z,y^2,0] c=[x^2,y^2,z^2,x^2+y^2,0])."""
+    x, y, z = [v % R for v in inputs]
+    log_n, n = 3, 8
+    a = [x, y, z, x * x % R, 0]
+    b = [x, y, z, y * y % R, 0]
+    c = [x * x % R, y * y % R, z * z % R, (x * x + y * y) % R, 0]
+    bl = blinders or [[11 + 3 * i + j for j in range(3)] for i in range(3)]
+    cols = [a + bl[0], b + bl[1], c + bl[2]]
+    mul, add, dummy = [0, 0, 1, 1, 0], [1, 1, 1, 0, 0], [0, 0, 0, 0, 0]
+    rows = [mul, mul, mul, add] + [dummy] * 4                      # builder.rs:318-324
+    q = {name: [rows[j][k] for j in range(n)] for k, name in enumerate(("q_l", "q_r", "q_o", "q_m", "q_c"))}
+    perm = list(range(3 * n))
+    # copy constraints (col,row): (0,0)~(1,0) (0,1)~(1,1) (0,2)~(1,2) (2,0)~(0,3) (2,1)~(1,3) (2,3)~(2,2)
+    for (ci, ri), (cj, rj) in (((0, 0), (1, 0)), ((0, 1), (1, 1)), ((0, 2), (1, 2)), ((2, 0), (0, 3)), ((2, 1), (1, 3)),
+                               ((2, 3), (2, 2))):
+        u, v = ri + ci * n, rj + cj * n
+        perm[u], perm[v] = perm[v], perm[u]
+    return log_n, cols, q, perm

@@ -146,3 +146,45 @@ def test_device_built_squaring_chain_matches_oracle_tables(ctx):
     assert O.fr_from_mont_limbs([int(v) for v in got["evals"][5]]) == 0
     sc.free()
     ctx.srs_free(sid)
+
+
+def _load_circuit(ctx, log_n, q_evals, perm):
+    n = 1 << log_n
+    _, sig = PO.compile_permutation(perm, n, log_n)
+    sel = [_up(ctx, O.interpolate(q_evals[k], log_n), n) for k in ("q_l", "q_r", "q_o", "q_m", "q_c")]
+    sgm = [_up(ctx, O.interpolate(s, log_n), n) for s in sig]
+    cid = ctx.circuit_load(log_n, sel, sgm)
+    for b in sel + sgm:
+        b.free()
+    return cid
+
+
+def test_readme_pythagorean_circuit(ctx):
+    """BASELINE config 1 / README.md:10-34 / plonk/src/builder/test.rs:25-37: inputs [3,4,5] prove and
+    'verify' (r(zeta) == 0, every element equal to the oracle's prove()); [3,4,6] must not"""
+    log_n, cols, q_evals, perm = PO.pythagorean_circuit([3, 4, 5])
+    n = 8
+    cid = _load_circuit(ctx, log_n, q_evals, perm)
+    sid = ctx.srs_generate(_limbs(0xC0FFEE), n + 3)          # Srs::random(n): 11 points
+    assert ctx.srs_len(sid) == 11
+    xy, inf = ctx.srs_download(sid)
+
+    def commit(coeffs):
+        out, oi = CO.msm_reference(fr_pack(coeffs) if coeffs else np.zeros((0, 4), dtype=np.uint64), xy, inf)
+        return g1_unpack_one(out, oi)
+
+    ref = PO.prove(log_n, cols, q_evals, perm, [0] * n, CH, ZETA, commit)
+    assert ref["rem"] == [] and ref["r_open"][1] == 0
+    got = _gpu_prove(ctx, sid, cid, cols, n)
+    pt = lambda t: g1_unpack_one(t[0], t[1])                   # noqa: E731
+    fr = lambda a: O.fr_from_mont_limbs([int(v) for v in a])   # noqa: E731
+    assert [pt(c) for c in got["commit"]] == ref["commit"] and pt(got["z_commit"]) == ref["z_commit"]
+    assert [pt(c) for c in got["t_commit"]] == ref["t_commit"]
+    assert [pt(w) for w in got["witness"]] == [o[0] for o in ref["open"]] + [ref["z_open"][0], ref["zw_open"][0], ref["r_open"][0]]
+    assert fr(got["evals"][5]) == 0
+    # bad inputs (circuit2_test_bad_inputs): the copy constraint c_3 ~ c_2 fails, the verifier's r(zeta) != 0
+    _, bad_cols, _, _ = PO.pythagorean_circuit([3, 4, 6])
+    bad = _gpu_prove(ctx, sid, cid, bad_cols, n)
+    assert fr(bad["evals"][5]) != 0
+    ctx.circuit_free(cid)
+    ctx.srs_free(sid)

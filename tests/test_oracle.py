@@ -145,3 +145,20 @@ def test_quotient_oracle_satisfies_the_reference_asserts():
     p = O.random_frs(3, 21)
     q, rem = PO.divide_by_vanishing_poly(p, 8)
     assert (O.poly_eval(q, x) * (pow(x, 8, O.R) - 1) + O.poly_eval(rem, x)) % O.R == O.poly_eval(p, x)
+
+
+def test_readme_circuit_oracle():
+    """SURVEY KAT-5: the README circuit accepts [3,4,5] (exact division, r(zeta) == 0) and rejects [3,4,6]"""
+    from oracle import plonk_oracle as PO
+
+    log_n, cols, q, perm = PO.pythagorean_circuit([3, 4, 5])
+    assert [c[:5] for c in cols] == [[3, 4, 5, 9, 0], [3, 4, 5, 16, 0], [9, 16, 25, 25, 0]]
+    n = 8
+    flat = {0: 8, 8: 0, 1: 9, 9: 1, 2: 10, 10: 2, 16: 3, 3: 16, 17: 11, 11: 17, 19: 18, 18: 19}
+    assert all(perm[k] == v for k, v in flat.items()) and sum(1 for i, p in enumerate(perm) if i != p) == 12
+    srs = O.srs_from_secret_fast(5, n + 3)
+    pr = PO.prove(log_n, cols, q, perm, [0] * n, (11, 22, 33), 44, lambda p: O.msm_naive(p, srs))
+    assert pr["rem"] == [] and pr["r_open"][1] == 0
+    _, bad, _, _ = PO.pythagorean_circuit([3, 4, 6])
+    pb = PO.prove(log_n, bad, q, perm, [0] * n, (11, 22, 33), 44, lambda p: O.msm_naive(p, srs))
+    assert pb["rem"] != [] or pb["r_open"][1] != 0

@@ -32,6 +32,11 @@ __global__ __launch_bounds__(256) void op_kernel(uint32_t* out, int iters) {
             if (OP == 6) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x[j]) : "v"(a));
             if (OP == 7) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[j]) : "v"(a));
             if (OP == 8) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(x[j]) : "v"(a));
+            if (OP == 9) asm volatile("v_lshrrev_b64 %0, 30, %0" : "+v"(acc[j]));
+            if (OP == 10) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[j]) : "v"(acc[(j + 1) % CH]));
+            if (OP == 11) asm volatile("v_alignbit_b32 %0, %1, %0, 30" : "+v"(x[j]) : "v"(a));
+            if (OP == 12) asm volatile("v_and_b32 %0, 0x3fffffff, %0" : "+v"(x[j]));
+            if (OP == 13) asm volatile("v_mov_b32 %0, %1" : "=v"(x[j]) : "v"(a));
         }
     }
     uint32_t s = 0;
@@ -114,9 +119,10 @@ int main() {
     const int blocks = prop.multiProcessorCount * 8, threads = 256, iters = 4096;
     uint32_t* out;
     CHK(hipMalloc(&out, (size_t)blocks * threads * 4 * 4));
-    const char* names[9] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add_co+addc (2 ops)", "v_fma_f64",
-                            "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_mul_hi_u32_u24"};
-    double ms[9];
+    const char* names[14] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add_co+addc (2 ops)", "v_fma_f64",
+                            "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_mul_hi_u32_u24", "v_lshrrev_b64", "v_lshl_add_u64",
+                            "v_alignbit_b32", "v_and_b32 (literal)", "v_mov_b32"};
+    double ms[14];
     ms[0] = time_ms([&] { hipLaunchKernelGGL(op_kernel<0>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
     ms[1] = time_ms([&] { hipLaunchKernelGGL(op_kernel<1>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
     ms[2] = time_ms([&] { hipLaunchKernelGGL(op_kernel<2>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
@@ -126,7 +132,12 @@ int main() {
     ms[6] = time_ms([&] { hipLaunchKernelGGL(op_kernel<6>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
     ms[7] = time_ms([&] { hipLaunchKernelGGL(op_kernel<7>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
     ms[8] = time_ms([&] { hipLaunchKernelGGL(op_kernel<8>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
-    for (int i = 0; i < 9; ++i) {
+    ms[9] = time_ms([&] { hipLaunchKernelGGL(op_kernel<9>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
+    ms[10] = time_ms([&] { hipLaunchKernelGGL(op_kernel<10>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
+    ms[11] = time_ms([&] { hipLaunchKernelGGL(op_kernel<11>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
+    ms[12] = time_ms([&] { hipLaunchKernelGGL(op_kernel<12>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
+    ms[13] = time_ms([&] { hipLaunchKernelGGL(op_kernel<13>, dim3(blocks), dim3(threads), 0, 0, out, iters); });
+    for (int i = 0; i < 14; ++i) {
         const double ops = (double)blocks * threads * iters * CH;
         const double waves = ops / 64.0;
         // cycles per wave-instruction per SIMD at the nominal clock: SIMDs * clk * t / wave-instrs
