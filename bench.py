@@ -89,18 +89,25 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # TYPLONK_BENCH_BACKEND=gloo lets several ranks share one GPU (validation of the sharded path on a
+    # 1-GPU box: RCCL refuses two ranks on the same device); the exchange then goes through host tensors
+    backend = os.environ.get("TYPLONK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or os.environ.get("TYPLONK_FORCE_COLLECTIVE") == "1":
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     log_n = args.log_n
     n = 1 << log_n
     srs_len = n + 3  # Srs::from_secret(s, gates) has gates + 3 points (kzg/src/srs.rs:31)
-    ctx = typlonk_amd.Context(local_rank)
+    ctx = typlonk_amd.Context(dev_index)
     ctx.set_profiling(True)
     secret = fr_mont_limbs(2)  # the reference's test secret (kzg/src/lib.rs:97)
-    sh = ShardedMsm(ctx, srs_len, rank, world, device)
+    sh = ShardedMsm(ctx, srs_len, rank, world, device if backend == "nccl" else torch.device("cpu"))
     sh.generate_srs(secret)
     use_tables = bool(args.tables) and (sh.hi - sh.lo) >= (1 << 19)
     if use_tables:
@@ -132,7 +139,7 @@ def main() -> None:
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -281,6 +288,17 @@ def main() -> None:
                 result["value"] = None
                 result["error"] = "GPU result differs from the oracle: number withheld"
 
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        # sharded result vs the reference's own test identity commit(p) == [p(s)]G (oracle = checker)
+        from oracle import coracle as CO
+
+        ps = CO.poly_eval(full.cpu().numpy().view(np.uint64), secret)
+        exp_xy, exp_inf = CO.g1_mul_generator(ps)
+        ok = bool((np.asarray(out_xy) == exp_xy).all() and out_inf == exp_inf)
+        result["parity"] = {"full_commit_identity": ok}
+        if not ok:
+            result["value"] = None
+            result["error"] = "sharded GPU result differs from the oracle: number withheld"
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
