@@ -499,7 +499,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     int hb = std::max<int>((int)c - 1 - lb_max, tables ? 0 : (int)lgm - 13);
     hb = std::max(0, std::min<int>(hb, (int)c - 1));
     const uint64_t nseg = (uint64_t)nsets << hb;
-    const uint64_t nblk = (m + 2047) / 2048;
+    const uint64_t nblk = msm_segsort_blocks(m);
     const uint64_t nmat = nseg * nblk;
     const bool segsort = !ctx->msm_legacy_sort && m <= (1u << 23) && nseg * 4 <= 64 * 1024 && nmat < (1ull << 31) &&
                          (!tables || W <= 16);

@@ -71,6 +71,7 @@ void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, ui
                        uint32_t* counts, hipStream_t s);
 void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor,
                  hipStream_t s);
+uint32_t msm_segsort_blocks(uint64_t m);  // workgroups of the level-1 passes for an m-term MSM
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,

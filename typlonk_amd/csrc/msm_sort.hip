@@ -157,10 +157,16 @@ __global__ __launch_bounds__(256) void scan_finish_kernel(const uint32_t* in, ui
 // exclusive scan over that matrix gives each (segment, workgroup) its private output range, so
 // the scatter needs only LDS atomics (for the rank inside the workgroup).
 // Level-1 entry: idx (23 bits) | sign << 23 | (b & (2^lb - 1)) << 24     (m <= 2^23)
-constexpr int MSM_CHUNK = 2048;  // scalars per workgroup = 8 per thread
+// scalars per workgroup: 2048 (8 per thread) up to 2^20 terms, growing with m beyond that so the
+// workgroup x segment matrix (nblk * nseg counters) stays bounded instead of growing like m^2
+__host__ __device__ inline uint32_t msm_chunk_for(uint64_t m) {
+    uint32_t chunk = 2048;
+    while (((uint64_t)chunk << 9) < m) chunk <<= 1;  // at most 512 workgroups
+    return chunk;
+}
 
 struct MsmShape {
-    uint32_t c, W, top_v, hb, lb, nseg, nblk;
+    uint32_t c, W, top_v, hb, lb, nseg, nblk, chunk;
     // level-1 entry layout: [i : ibits][j : jbits][sign : 1][low bucket bits : lb]
     uint32_t ibits, jbits;
     // fixed-base table mode (tlen != 0): base (j, i) lives at gather index j * tlen + i and all windows
@@ -211,8 +217,8 @@ __global__ __launch_bounds__(256) void msm_seg_hist_kernel(const Fr* scalars, ui
     extern __shared__ uint32_t seg_h[];
     for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) seg_h[s] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * MSM_CHUNK;
-    for (int e = 0; e < MSM_CHUNK / 256; ++e) {
+    const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
+    for (uint32_t e = 0; e < sh.chunk / 256; ++e) {
         const uint64_t i = base + threadIdx.x + 256 * e;
         if (i < m) {
             uint32_t v[8];
@@ -232,9 +238,9 @@ __global__ __launch_bounds__(256) void msm_seg_scatter_kernel(const Fr* scalars,
     uint32_t* cur = seg_sm;             // running position of this workgroup inside each segment
     for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) cur[s] = blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * MSM_CHUNK;
+    const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
     const uint32_t lmask = (1u << sh.lb) - 1;
-    for (int e = 0; e < MSM_CHUNK / 256; ++e) {
+    for (uint32_t e = 0; e < sh.chunk / 256; ++e) {
         const uint64_t i = base + threadIdx.x + 256 * e;
         if (i < m) {
             uint32_t v[8];
@@ -403,6 +409,8 @@ void launch_exclusive_scan(const uint32_t* in, uint64_t n, uint32_t* block_sums,
     hipLaunchKernelGGL(scan_finish_kernel, dim3(nblk), dim3(256), 0, s, in, n, block_sums, out, out2);
 }
 
+uint32_t msm_segsort_blocks(uint64_t m) { return (uint32_t)((m + msm_chunk_for(m) - 1) / msm_chunk_for(m)); }
+
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
@@ -418,7 +426,8 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
     sh.tlen = tlen;
     sh.nsets = nsets;
     sh.nseg = (tlen ? nsets : W) << hb;
-    sh.nblk = (uint32_t)((m + MSM_CHUNK - 1) / MSM_CHUNK);
+    sh.chunk = msm_chunk_for(m);
+    sh.nblk = (uint32_t)((m + sh.chunk - 1) / sh.chunk);
     const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
     hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(256), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
                        blk_hist);
