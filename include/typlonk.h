@@ -108,7 +108,8 @@ int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int in
  * produced by typlonk_ntt_fr_dev(inverse): the wire polynomials a, b, c (proof.rs:50), the grand
  * product Z (:127), the five selector polynomials q_l q_r q_o q_m q_c (builder.rs:84-88), the three
  * sigma polynomials (proof.rs:334-338) and the public-input polynomial (:105).  Z(wX) is derived
- * internally.  Scalars are 4-limb Montgomery Fr: challenges alpha, beta, gamma (proof.rs:111, 133) and
+ * internally; public_inputs may be NULL (= the zero polynomial, public inputs [0] as in the reference's
+ * README and tests).  Scalars are 4-limb Montgomery Fr: challenges alpha, beta, gamma (proof.rs:111, 133) and
  * the identity-permutation cosets k_0..k_2 (permutation/src/lib.rs:141-154; 2, 3, 4 in the reference).
  * t_out must hold >= 4n elements; on return its first 3n hold the coefficients of t (degree <= 3n - 4;
  * the three commitments of SlicedPoly<3> are MSMs of [0,n), [n,2n), [2n,3n)), the rest is zero.
@@ -157,7 +158,7 @@ int typlonk_lincomb_dev(typlonk_ctx* ctx, const typlonk_buf* const* polys, const
  * split at its two Fiat-Shamir squeezes (challenges.rs is CPU-side and out of scope, so the caller
  * supplies the challenges):
  *   round1  columns (EVALUATIONS, n each, blinding rows included -- proof.rs:43-49) and the public-input
- *           column -> a, b, c, PI by iNTT (:50, :105) and the commitments [a], [b], [c] (:107-110)
+ *           column (NULL = all zero) -> a, b, c, PI by iNTT (:50, :105) and the commitments [a], [b], [c] (:107-110)
  *   round2  beta, gamma (:111) -> grand product Z (:119), iNTT (:127), [Z] (:129)
  *   round3  alpha, zeta (:133-136) -> quotient (:139), openings of a, b, c, Z at zeta and Z at zeta*w (:147-163),
  *           linearisation polynomial r and its opening (:165-175), [t_lo], [t_mid], [t_hi] (:181)

@@ -103,6 +103,26 @@ def test_prove_2_12_self_checks(ctx):
     ctx.srs_free(sid)
 
 
+def test_null_public_inputs_equal_zero_column(ctx):
+    """public_inputs = NULL is the zero polynomial: identical proof to an explicit all-zero column"""
+    n, cols, q_evals, perm, cid = _setup(ctx, 5)
+    sid = ctx.srs_generate(_limbs(7), n + 3)
+    a = _gpu_prove(ctx, sid, cid, cols, n)                       # explicit zero column
+    wires = [_up(ctx, c, n) for c in cols]
+    alpha, beta, gamma = CH
+    b = ctx.prove(sid, cid, wires, None, [_limbs(k) for k in PO.COSETS],
+                  lambda c: (_limbs(beta), _limbs(gamma)), lambda c: (_limbs(alpha), _limbs(ZETA)))
+    for key in ("commit", "t_commit", "witness"):
+        for (x, xi), (y, yi) in zip(a[key], b[key]):
+            assert (x == y).all() and xi == yi
+    for x, y in zip(a["evals"], b["evals"]):
+        assert (x == y).all()
+    for w in wires:
+        w.free()
+    ctx.circuit_free(cid)
+    ctx.srs_free(sid)
+
+
 def test_prove_rejects_wrong_round_order_and_short_srs(ctx):
     from typlonk_amd.capi import TyplonkError, ERR_LENGTH
 

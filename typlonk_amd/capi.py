@@ -350,8 +350,8 @@ class Context:
         pr = C.c_void_p()
         cxy = ((C.c_uint64 * 12) * 3)()
         cinf = (C.c_uint8 * 3)()
-        self._chk(lib.typlonk_prover_round1(self.h, sid, circuit, w, pi_evals.handle, C.byref(pr), C.byref(cxy),
-                                            C.byref(cinf)))
+        self._chk(lib.typlonk_prover_round1(self.h, sid, circuit, w, pi_evals.handle if pi_evals is not None else None,
+                                            C.byref(pr), C.byref(cxy), C.byref(cinf)))
         try:
             commits = [(np.array(cxy[i], dtype=np.uint64), int(cinf[i])) for i in range(3)]
             beta, gamma = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in challenge12(commits)]
@@ -398,7 +398,7 @@ class Context:
         for i in range(5):
             if not circuit:
                 a.selectors[i] = selectors[i].handle.value
-        a.public_inputs = pi.handle.value
+        a.public_inputs = pi.handle.value if pi is not None else None
         for name, val in (("alpha", alpha), ("beta", beta), ("gamma", gamma)):
             arr = getattr(a, name)
             for j, limb in enumerate(np.asarray(val, dtype=np.uint64).reshape(4)):

@@ -56,8 +56,7 @@ class SquaringChain:
         bl = [[int(v) for v in rng.integers(1, 1 << 62, size=3)] for _ in range(3)]
         cols = [xs[:g] + bl[0], xs[:g] + bl[1], xs[1:g + 1] + bl[2]]
         self.wire_evals = [_to_montgomery(ctx, _canon_limbs(c)) for c in cols]
-        self.pi_evals = ctx.alloc(n)
-        self.pi_evals.zero()
+        self.pi_evals = None   # public inputs [0] (README.md:31): the zero polynomial
         # ---- selectors (evaluations): q_o = q_m = 1 on the gate rows, everything else 0 -------------------
         one = fr_mont_limbs(1)
         sel_ones = np.zeros((n, 4), dtype=np.uint64)
@@ -99,5 +98,5 @@ class SquaringChain:
 
     def free(self):
         self.ctx.circuit_free(self.circuit)
-        for b in self.wire_evals + [self.pi_evals]:
+        for b in self.wire_evals:
             b.free()

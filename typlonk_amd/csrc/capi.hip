@@ -1008,8 +1008,11 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
         cached = it->second.ext;
     }
     const int n_in = cached ? 5 : 13;
-    for (int k = 0; k < n_in; ++k)
+    const bool has_pi = args->public_inputs != nullptr;  // NULL = zero polynomial (public inputs [0])
+    for (int k = 0; k < n_in; ++k) {
+        if (k == 4 && !has_pi) continue;
         if (!in[k] || in[k]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "quotient input shorter than n");
+    }
     if (t_out->n < n4) return fail(ctx, TYPLONK_ERR_RANGE, "t_out must hold 4n elements");
     int rc = ensure(ctx, ctx->quot_ext, (size_t)(cached ? 5 : 14) * n4 * sizeof(Fr));
     if (rc) return rc;
@@ -1020,8 +1023,10 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     const bool prof = ctx->profiling;
     ctx->profiling = false;
     const Fr ninv = fe_inv(fr_from_u64(n));
-    for (int k = 0; k < (cached ? 5 : 14) && !rc; ++k)
+    for (int k = 0; k < (cached ? 5 : 14) && !rc; ++k) {
+        if (k == 4 && !has_pi) continue;
         rc = quotient_extend(ctx, ext + (uint64_t)k * n4, k < 13 ? in[k]->d : nullptr, &ninv, n, log4);
+    }
     if (rc) {
         ctx->profiling = prof;
         return rc;
@@ -1029,7 +1034,7 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     QuotientArgs qa{};
     for (int k = 0; k < 3; ++k) qa.wires[k] = ext + (uint64_t)k * n4;
     qa.z = ext + 3 * n4;
-    qa.pi = ext + 4 * n4;
+    qa.pi = has_pi ? ext + 4 * n4 : nullptr;
     const Fr* cbase = cached ? cached : ext + 5 * n4;
     for (int k = 0; k < 5; ++k) qa.sel[k] = cbase + (uint64_t)k * n4;
     for (int k = 0; k < 3; ++k) qa.sigma[k] = cbase + (uint64_t)(5 + k) * n4;
@@ -1182,6 +1187,7 @@ struct typlonk_prover {
     Fr* mem = nullptr;  // one allocation, carved below
     Fr *ev[3], *co[3], *pi, *z, *t, *q[6], *r;
     Fr beta, gamma, k[3];
+    bool has_pi = true;
     int round = 0;
 };
 
@@ -1207,8 +1213,7 @@ int prover_open(typlonk_prover* p, const Fr* poly, uint64_t m, const Fr& z, Fr* 
 int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
                           const typlonk_buf* pi_evals, typlonk_prover** out, uint64_t commit_xy[3][12],
                           uint8_t commit_inf[3]) {
-    if (!ctx || !wire_evals || !pi_evals || !out || !commit_xy || !commit_inf)
-        return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (!ctx || !wire_evals || !out || !commit_xy || !commit_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
     auto ci = ctx->circuits.find(circuit_id);
     if (ci == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
@@ -1220,7 +1225,7 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     if (n > (1u << 22)) return fail(ctx, TYPLONK_ERR_LENGTH, "prover supports up to 2^22 rows");
     for (int i = 0; i < 3; ++i)
         if (!wire_evals[i] || wire_evals[i]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "wire column shorter than n");
-    if (pi_evals->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "public-input column shorter than n");
+    if (pi_evals && pi_evals->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "public-input column shorter than n");
     if (ctx->prover_busy) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "a proof is already in flight on this context");
     rc = ensure(ctx, ctx->prover_mem, (uint64_t)19 * n * sizeof(Fr));  // 3+3+1+1+4+6+1 vectors, kept across proofs
     if (rc) return rc;
@@ -1249,7 +1254,8 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
         hipMemcpyAsync(p->co[i], wire_evals[i]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
         rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false);
     }
-    if (!rc) {
+    p->has_pi = pi_evals != nullptr;  // NULL: public inputs [0] -> the zero polynomial
+    if (!rc && p->has_pi) {
         hipMemcpyAsync(p->pi, pi_evals->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
         rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
     }
@@ -1323,7 +1329,7 @@ int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint
         typlonk_quotient_args qa{};
         for (int i = 0; i < 3; ++i) qa.wires[i] = &b[i];
         qa.z = &b[3];
-        qa.public_inputs = &b[4];
+        qa.public_inputs = p->has_pi ? &b[4] : nullptr;
         memcpy(qa.alpha, alpha, 32);
         memcpy(qa.beta, p->beta.v, 32);
         memcpy(qa.gamma, p->gamma.v, 32);
@@ -1342,7 +1348,8 @@ int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint
     Fr s0, s1, pi_z;
     if (!rc) rc = prover_open(p, ce.coef + 5 * n, n, ze, nullptr, &s0);   // sigma_0(zeta)
     if (!rc) rc = prover_open(p, ce.coef + 6 * n, n, ze, nullptr, &s1);   // sigma_1(zeta)
-    if (!rc) rc = prover_open(p, p->pi, n, ze, nullptr, &pi_z);           // public_eval, proof.rs:138
+    pi_z = Fr::zero();
+    if (!rc && p->has_pi) rc = prover_open(p, p->pi, n, ze, nullptr, &pi_z);  // public_eval, proof.rs:138
     if (!rc) {
         const Fr one = Fr::one();
         Fr zn = ze;  // zeta^n

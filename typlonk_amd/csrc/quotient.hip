@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void quotient_pointwise_kernel(QuotientArgs a)
     line1 = fe_sub(line1, fe_mul(q_ld(a.sel[2] + i), wc));
     line1 = fe_add(line1, fe_mul(fe_mul(q_ld(a.sel[3] + i), wa), wb));
     line1 = fe_add(line1, q_ld(a.sel[4] + i));
-    line1 = fe_add(line1, q_ld(a.pi + i));
+    if (a.pi) line1 = fe_add(line1, q_ld(a.pi + i));  // no public-input polynomial = the zero polynomial
     // x_i = g * w_{4n}^i from the two-level power table of w_{4n}
     const Fr x = fe_mul(a.g, fe_mul(q_ld(a.w_lo + (i & ((1ull << a.w_h) - 1))), q_ld(a.w_hi + (i >> a.w_h))));
     const Fr bx = fe_mul(a.beta, x);
