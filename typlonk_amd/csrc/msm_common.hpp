@@ -23,7 +23,7 @@ namespace ty {
 
 constexpr uint32_t MSM_SKIP = 0xffffffffu;
 constexpr int MSM_THREADS = 256;
-constexpr int MSM_ACC_THREADS = 64;
+constexpr int MSM_ACC_THREADS = 128;
 
 // HBM form of a field element: 12 packed 32-bit words (fq30.hpp); three 16-byte accesses.
 __device__ __forceinline__ Fq30 ld_fq(const uint32_t* p) {
