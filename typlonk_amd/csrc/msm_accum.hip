@@ -92,7 +92,7 @@ void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uin
 }
 void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist514, const uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s) {
-    hipLaunchKernelGGL(msm_heavy_kernel, dim3(2048), dim3(MSM_ACC_THREADS), 0, s, points, sorted, hist514, tasks, partial);
+    hipLaunchKernelGGL(msm_heavy_kernel, dim3(256), dim3(MSM_ACC_THREADS), 0, s, points, sorted, hist514, tasks, partial);
     hipLaunchKernelGGL(msm_heavy_combine_kernel, dim3(64), dim3(64), 0, s, hist514, heavy, partial, buckets);
 }
 
