@@ -4,6 +4,8 @@
 namespace ty {
 
 // acc(96) += a*b : one mad + one carry-capture add
+#undef TY_MAC_VV
+#undef TY_MAC_VS
 #define TY_MAC_VV(lo, hi, a, b) asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc")
 #define TY_MAC_VS(lo, hi, a, b) asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "s"(b) : "vcc")
 
