@@ -258,6 +258,16 @@ def main() -> None:
         result["prove_ms"] = (time.perf_counter() - t1) / reps * 1e3
         result["prove_valid"] = bool((proof["evals"][5] == zero_limbs).all())   # r(zeta) == 0, proof.rs:234-235
         result["prove_config"] = f"squaring chain, {chain.gates} gates, n = 2^{log_n}, 7 commitments + 6 openings"
+        # same proof with the openings at zeta batched (typlonk_prover_round3_evals / round4_batched): 9 MSMs
+        run_b = lambda: ctx.prove(sh.sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731
+                                  lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]), challenge_v=lambda e: ch[1])
+        run_b()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            run_b()
+        torch.cuda.synchronize()
+        result["prove_batched_openings_ms"] = (time.perf_counter() - t1) / reps * 1e3
         chain.free()
 
         if not args.no_cpu_baseline:

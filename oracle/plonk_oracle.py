@@ -244,7 +244,7 @@ def prove(log_n, cols, q_evals, perm, pi_evals, challenges, zeta, commit):
     r_open = open_(r, zeta)                                                   # :175
     t_commit = [commit(s) for s in t_slices]                                  # :181
     return {"commit": commitments, "open": openings, "z_commit": z_commit, "z_open": z_open, "zw_open": zw_open,
-            "t_commit": t_commit, "r_open": r_open, "r": r, "t": t, "rem": rem}
+            "t_commit": t_commit, "r_open": r_open, "r": r, "t": t, "rem": rem, "wires": wires, "z": z}
 
 
 # ---- the README circuit (a*a + b*b == c*c), SURVEY.md KAT-5 --------------------------------------------
@@ -269,3 +269,15 @@ def pythagorean_circuit(inputs, blinders=None):
         u, v = ri + ci * n, rj + cj * n
         perm[u], perm[v] = perm[v], perm[u]
     return log_n, cols, q, perm
+
+
+def batched_opening(polys, v, zeta, commit):
+    """Batched KZG opening of `polys` (coefficient lists) at zeta with challenge v -- the reference's to-do
+    (/root/reference/README.md:4 "opening batching"), stated with the reference's own open()
+    (/root/reference/kzg/src/lib.rs:55-64) applied to F = sum_i v^i p_i.  Returns (W, F(zeta))."""
+    f, pw = [], 1
+    for p in polys:
+        f = p_add(f, p_scale(p, pw))
+        pw = pw * v % R
+    q, y = O.poly_div_linear(f, zeta)
+    return commit(q), y

@@ -35,12 +35,16 @@ def _setup(ctx, log_n, x0=3):
     return n, cols, q_evals, perm, cid
 
 
-def _gpu_prove(ctx, sid, cid, cols, n, pi_evals=None):
+V_BATCH = 0x7E57AB1E0F0F0F0F1234
+
+
+def _gpu_prove(ctx, sid, cid, cols, n, pi_evals=None, batched=False):
     wires = [_up(ctx, c, n) for c in cols]
     pi = _up(ctx, pi_evals or [0] * n, n)
     alpha, beta, gamma = CH
     proof = ctx.prove(sid, cid, wires, pi, [_limbs(k) for k in PO.COSETS],
-                      lambda commits: (_limbs(beta), _limbs(gamma)), lambda commits: (_limbs(alpha), _limbs(ZETA)))
+                      lambda commits: (_limbs(beta), _limbs(gamma)), lambda commits: (_limbs(alpha), _limbs(ZETA)),
+                      challenge_v=(lambda evals: _limbs(V_BATCH)) if batched else None)
     for b in wires + [pi]:
         b.free()
     return proof
@@ -70,6 +74,66 @@ def test_prove_equals_reference_flow(ctx, log_n):
     assert [pt(w) for w in got["witness"]] == ref_w
     assert [fr(e) for e in got["evals"]] == ref_e
     assert fr(got["evals"][5]) == 0                      # the verifier's r(zeta) == 0 (proof.rs:234-235)
+    ctx.circuit_free(cid)
+    ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("log_n", [3, 5])
+def test_batched_openings_equal_oracle_and_the_combination_of_the_six(ctx, log_n):
+    """round3_evals + round4_batched: same commitments and evaluations as the six-opening proof; W[0] is
+    the oracle's open() of a + v b + v^2 c + v^3 Z + v^4 r AND sum_i v^i W_i of the reference-shaped
+    witnesses (division by X - zeta is linear); W[1] is the witness of Z at zeta*w"""
+    n, cols, q_evals, perm, cid = _setup(ctx, log_n)
+    sid = ctx.srs_generate(_limbs(0xFEEDFACE12345), n + 3)
+    xy, inf = ctx.srs_download(sid)
+
+    def commit(coeffs):
+        out, oi = CO.msm_reference(fr_pack(coeffs) if coeffs else np.zeros((0, 4), dtype=np.uint64), xy, inf)
+        return g1_unpack_one(out, oi)
+
+    ref = PO.prove(log_n, cols, q_evals, perm, [0] * n, CH, ZETA, commit)
+    got = _gpu_prove(ctx, sid, cid, cols, n, batched=True)
+    six = _gpu_prove(ctx, sid, cid, cols, n)
+    pt = lambda t: g1_unpack_one(t[0], t[1])              # noqa: E731
+    assert got["batched"] and len(got["witness"]) == 2
+    for key in ("commit", "t_commit"):
+        assert [pt(c) for c in got[key]] == [pt(c) for c in six[key]] == ref[key]
+    assert pt(got["z_commit"]) == ref["z_commit"]
+    assert all((x == y).all() for x, y in zip(got["evals"], six["evals"]))
+    w_ref, y_ref = PO.batched_opening(ref["wires"] + [ref["z"], ref["r"]], V_BATCH, ZETA, commit)
+    assert pt(got["witness"][0]) == w_ref
+    fr = lambda a: O.fr_from_mont_limbs([int(v) for v in a])  # noqa: E731
+    ev = [fr(e) for e in got["evals"]]
+    assert y_ref == sum(pow(V_BATCH, i, O.R) * ev[j] for i, j in enumerate((0, 1, 2, 3, 5))) % O.R
+    comb = None
+    for i, j in enumerate((0, 1, 2, 3, 5)):
+        term = O.g1_mul(pt(six["witness"][j]), pow(V_BATCH, i, O.R))
+        comb = term if comb is None else O.g1_add(comb, term)
+    assert pt(got["witness"][0]) == comb
+    assert pt(got["witness"][1]) == pt(six["witness"][4]) == ref["zw_open"][0]
+    ctx.circuit_free(cid)
+    ctx.srs_free(sid)
+
+
+def test_batched_round_order_is_enforced(ctx):
+    import ctypes as C
+    from typlonk_amd.capi import TyplonkError, ERR_INVALID_ARG
+
+    n, cols, q_evals, perm, cid = _setup(ctx, 3)
+    sid = ctx.srs_generate(_limbs(2), n + 3)
+    wires = [_up(ctx, c, n) for c in cols]
+    lib = ctx.lib
+    pr = C.c_void_p()
+    cxy, cinf = ((C.c_uint64 * 12) * 3)(), (C.c_uint8 * 3)()
+    w = (C.c_void_p * 3)(*[b.handle.value for b in wires])
+    ctx._chk(lib.typlonk_prover_round1(ctx.h, sid, cid, w, None, C.byref(pr), C.byref(cxy), C.byref(cinf)))
+    v = _limbs(5)
+    wxy, winf = ((C.c_uint64 * 12) * 2)(), (C.c_uint8 * 2)()
+    rc = lib.typlonk_prover_round4_batched(pr, v.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(wxy), C.byref(winf))
+    assert rc == ERR_INVALID_ARG
+    lib.typlonk_prover_free(pr)
+    for b in wires:
+        b.free()
     ctx.circuit_free(cid)
     ctx.srs_free(sid)
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_precompute", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
     "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
-    "typlonk_prover_round3", "typlonk_prover_free", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_prover_round3", "typlonk_prover_round3_evals", "typlonk_prover_round4_batched", "typlonk_prover_free", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
@@ -44,6 +44,11 @@ class ProofTail(C.Structure):
     """typlonk_proof_tail"""
     _fields_ = [("t_xy", (C.c_uint64 * 12) * 3), ("t_inf", C.c_uint8 * 3), ("w_xy", (C.c_uint64 * 12) * 6),
                 ("w_inf", C.c_uint8 * 6), ("evals", (C.c_uint64 * 4) * 6)]
+
+
+class ProofEvals(C.Structure):
+    """typlonk_proof_evals"""
+    _fields_ = [("t_xy", (C.c_uint64 * 12) * 3), ("t_inf", C.c_uint8 * 3), ("evals", (C.c_uint64 * 4) * 6)]
 
 
 _lib = None
@@ -90,6 +95,8 @@ def load_library() -> C.CDLL:
                                           C.POINTER((C.c_uint64 * 12) * 3), C.POINTER(C.c_uint8 * 3)]
     lib.typlonk_prover_round2.argtypes = [vp, u64p, u64p, C.POINTER((C.c_uint64 * 4) * 3), u64p, u8p]
     lib.typlonk_prover_round3.argtypes = [vp, u64p, u64p, C.POINTER(ProofTail)]
+    lib.typlonk_prover_round3_evals.argtypes = [vp, u64p, u64p, C.POINTER(ProofEvals)]
+    lib.typlonk_prover_round4_batched.argtypes = [vp, u64p, C.POINTER((C.c_uint64 * 12) * 2), C.POINTER(C.c_uint8 * 2)]
     lib.typlonk_prover_free.argtypes = [vp]
     lib.typlonk_prover_free.restype = None
     lib.typlonk_circuit_load.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -341,10 +348,12 @@ class Context:
             cp = _u64p(cc)
         self._chk(self.lib.typlonk_lincomb_dev(self.h, ptrs, sc, k, cp, n, out.handle))
 
-    def prove(self, sid: int, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34):
+    def prove(self, sid: int, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34, challenge_v=None):
         """Three-round prover session.  challenge12(commitments) -> (beta, gamma) and
         challenge34(commitments + [Z]) -> (alpha, zeta) are callables returning 4-limb arrays (the
-        caller's Fiat-Shamir).  Returns a dict of numpy arrays in the C-ABI form."""
+        caller's Fiat-Shamir).  Returns a dict of numpy arrays in the C-ABI form.
+        challenge_v(evals) -> v selects the batched-opening shape (round3_evals + round4_batched):
+        "witness" then holds [W at zeta of a + v b + v^2 c + v^3 Z + v^4 r, W of Z at zeta*w]."""
         lib = self.lib
         w = (C.c_void_p * 3)(*[b.handle.value for b in wire_evals])
         pr = C.c_void_p()
@@ -364,6 +373,20 @@ class Context:
             self._chk(lib.typlonk_prover_round2(pr, _u64p(beta), _u64p(gamma), C.byref(ks), _u64p(zxy), _u8p(zinf)))
             alpha, zeta = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
                            for x in challenge34(commits + [(zxy, int(zinf[0]))])]
+            if challenge_v is not None:
+                pe = ProofEvals()
+                self._chk(lib.typlonk_prover_round3_evals(pr, _u64p(alpha), _u64p(zeta), C.byref(pe)))
+                evals = [np.array(pe.evals[i], dtype=np.uint64) for i in range(6)]
+                v = np.ascontiguousarray(challenge_v(evals), dtype=np.uint64).reshape(4)
+                wxy = ((C.c_uint64 * 12) * 2)()
+                winf = (C.c_uint8 * 2)()
+                self._chk(lib.typlonk_prover_round4_batched(pr, _u64p(v), C.byref(wxy), C.byref(winf)))
+                return {
+                    "commit": commits, "z_commit": (zxy, int(zinf[0])),
+                    "t_commit": [(np.array(pe.t_xy[i], dtype=np.uint64), int(pe.t_inf[i])) for i in range(3)],
+                    "witness": [(np.array(wxy[i], dtype=np.uint64), int(winf[i])) for i in range(2)],
+                    "evals": evals, "batched": True,
+                }
             tail = ProofTail()
             self._chk(lib.typlonk_prover_round3(pr, _u64p(alpha), _u64p(zeta), C.byref(tail)))
         finally:

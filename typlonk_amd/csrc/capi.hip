@@ -1189,6 +1189,11 @@ struct typlonk_prover {
     Fr beta, gamma, k[3];
     bool has_pi = true;
     int round = 0;
+    // batched-opening flow (round3_evals / round4_batched): zeta and the witness of Z at zeta*w
+    bool evals_only = false;
+    Fr zeta;
+    uint64_t zw_xy[12];
+    uint8_t zw_inf = 0;
 };
 
 namespace {
@@ -1306,8 +1311,13 @@ int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint6
     return rc;
 }
 
-int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4], typlonk_proof_tail* out) {
-    if (!p || !alpha || !zeta || !out) return TYPLONK_ERR_INVALID_ARG;
+namespace {
+// Round 3 in both shapes.  tail != NULL: the reference's six separate openings (proof.rs:147-175).
+// evals != NULL: evaluations only -- the quotients (p - p(zeta)) / (X - zeta) are not formed here; after
+// the caller has squeezed v from the evaluations, round4_batched opens a + v b + v^2 c + v^3 Z + v^4 r once.
+int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4], typlonk_proof_tail* out,
+                       typlonk_proof_evals* evals_out) {
+    const bool batched = evals_out != nullptr;
     typlonk_ctx* ctx = p->ctx;
     if (p->round != 2) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round3 must follow round2");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1341,8 +1351,8 @@ int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint
     Fr ev[6];
     const Fr w = fr_domain_root(log_n);
     const Fr zw = fe_mul(ze, w);
-    for (int i = 0; i < 3 && !rc; ++i) rc = prover_open(p, p->co[i], n, ze, p->q[i], &ev[i]);
-    if (!rc) rc = prover_open(p, p->z, n, ze, p->q[3], &ev[3]);
+    for (int i = 0; i < 3 && !rc; ++i) rc = prover_open(p, p->co[i], n, ze, batched ? nullptr : p->q[i], &ev[i]);
+    if (!rc) rc = prover_open(p, p->z, n, ze, batched ? nullptr : p->q[3], &ev[3]);
     if (!rc) rc = prover_open(p, p->z, n, zw, p->q[4], &ev[4]);
     // ---- linearisation polynomial (proof.rs:376-439) ----
     Fr s0, s1, pi_z;
@@ -1389,9 +1399,26 @@ int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
     }
-    if (!rc) rc = prover_open(p, p->r, n, ze, p->q[5], &ev[5]);          // proof.rs:175
+    if (!rc) rc = prover_open(p, p->r, n, ze, batched ? nullptr : p->q[5], &ev[5]);          // proof.rs:175
+    if (!rc && batched) {
+        // the quotient slices and the one witness that does not depend on v: Z at zeta*w
+        const Fr* polys[4] = {p->t, p->t + n, p->t + 2 * n, p->q[4]};
+        const size_t m[4] = {n, n, n > 3 ? n - 3 : 0, n - 1};
+        uint64_t xy[4][12];
+        uint8_t inf[4];
+        rc = prover_commit_batch(p, polys, m, 4, &xy[0][0], inf);
+        if (!rc) {
+            memcpy(evals_out->t_xy, xy, 3 * 96);
+            memcpy(evals_out->t_inf, inf, 3);
+            memcpy(p->zw_xy, xy[3], 96);
+            p->zw_inf = inf[3];
+            for (int i = 0; i < 6; ++i) memcpy(evals_out->evals[i], ev[i].v, 32);
+            p->zeta = ze;
+            p->evals_only = true;
+        }
+    }
     // ---- the nine remaining commitments in one batch: 6 opening witnesses + 3 quotient slices (:181) ----
-    if (!rc) {
+    if (!rc && !batched) {
         const Fr* polys[9] = {p->q[0], p->q[1], p->q[2], p->q[3], p->q[4], p->q[5], p->t, p->t + n, p->t + 2 * n};
         const size_t m[9] = {n - 1, n - 1, n - 1, n - 1, n - 1, n - 1, n, n, n > 3 ? n - 3 : 0};
         uint64_t xy[9][12];
@@ -1407,6 +1434,61 @@ int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint
     }
     ctx->profiling = prof;
     if (!rc) p->round = 3;
+    return rc;
+}
+}  // namespace
+
+int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4], typlonk_proof_tail* out) {
+    if (!p || !alpha || !zeta || !out) return TYPLONK_ERR_INVALID_ARG;
+    return prover_round3_core(p, alpha, zeta, out, nullptr);
+}
+
+int typlonk_prover_round3_evals(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4],
+                                typlonk_proof_evals* out) {
+    if (!p || !alpha || !zeta || !out) return TYPLONK_ERR_INVALID_ARG;
+    return prover_round3_core(p, alpha, zeta, nullptr, out);
+}
+
+int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], uint64_t w_xy[2][12], uint8_t w_inf[2]) {
+    if (!p || !v || !w_xy || !w_inf) return TYPLONK_ERR_INVALID_ARG;
+    typlonk_ctx* ctx = p->ctx;
+    if (p->round != 3 || !p->evals_only) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round4_batched must follow round3_evals");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t n = p->n;
+    const bool prof = ctx->profiling;
+    ctx->profiling = false;
+    // F = a + v b + v^2 c + v^3 Z + v^4 r; division by (X - zeta) is linear, so its witness is
+    // sum_i v^i W_i of the six-opening proof
+    LincombArgs la{};
+    const Fr* polys[5] = {p->co[0], p->co[1], p->co[2], p->z, p->r};
+    Fr vv, pw = Fr::one();
+    memcpy(vv.v, v, 32);
+    for (int i = 0; i < 5; ++i) {
+        la.poly[i] = polys[i];
+        la.scalar[i] = pw;
+        pw = fe_mul(pw, vv);
+    }
+    la.terms = 5;
+    la.constant = Fr::zero();
+    la.out = p->q[5];
+    la.n = n;
+    launch_lincomb(la, ctx->stream);
+    int rc = TYPLONK_OK;
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
+    Fr y;
+    if (!rc) rc = prover_open(p, p->q[5], n, p->zeta, p->q[0], &y);
+    if (!rc) {
+        const Fr* one[1] = {p->q[0]};
+        const size_t m[1] = {n - 1};
+        rc = prover_commit_batch(p, one, m, 1, &w_xy[0][0], &w_inf[0]);
+    }
+    if (!rc) {
+        memcpy(w_xy[1], p->zw_xy, 96);
+        w_inf[1] = p->zw_inf;
+        p->round = 4;
+    }
+    ctx->profiling = prof;
     return rc;
 }
 
