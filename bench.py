@@ -109,7 +109,7 @@ def main() -> None:
     secret = fr_mont_limbs(2)  # the reference's test secret (kzg/src/lib.rs:97)
     sh = ShardedMsm(ctx, srs_len, rank, world, device if backend == "nccl" else torch.device("cpu"))
     sh.generate_srs(secret)
-    use_tables = bool(args.tables) and (sh.hi - sh.lo) >= (1 << 19)
+    use_tables = bool(args.tables) and (sh.hi - sh.lo) >= (1 << 16)
     if use_tables:
         ctx.srs_precompute(sh.sid, args.tables)   # setup, like the SRS upload itself: the SRS is fixed per circuit
 

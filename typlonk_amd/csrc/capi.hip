@@ -55,13 +55,17 @@ struct ProfStage {
 // MSMs (prove() issues them in groups: 3 wire commitments, 5-6 openings, 3 quotient slices --
 // plonk/src/proof.rs:107-110, 147-175, 181) can overlap one MSM's host-side finish (window combine, affine
 // normalisation) and kernel tail with the next one's sort + accumulate.
+constexpr size_t HOST_WIN_POINTS = 32 * 2 * RC_NB;  // up to 32 bucket sets x {rows, columns} x RC_NB bit planes
+
 struct MsmWs {
     DevBuf keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist, blk_hist, blk_base, heavy, tasks,
-        hpart;
+        hpart, rc_sums, rc_bits, rc_out;
     hipStream_t stream = nullptr;
-    uint32_t* host_wins = nullptr;  // pinned, 64 windows x 48 words
+    uint32_t* host_wins = nullptr;  // pinned, HOST_WIN_POINTS x 48 words
     bool pending = false;
     uint32_t W = 0, c = 0;
+    bool rc = false;                // row/column reduction: host_wins holds bit planes (launch.hpp)
+    RcShape rcs{};
     uint64_t* out_xy = nullptr;
     uint8_t* out_inf = nullptr;
 };
@@ -97,6 +101,7 @@ struct typlonk_ctx {
     std::vector<std::pair<const char*, float>> prof_result;
     int msm_c_override = 0;
     bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
+    bool msm_tree_reduce = false;  // TYPLONK_MSM_REDUCE=running: running-sum + small-multiple reduction (first version)
 };
 
 namespace {
@@ -432,7 +437,7 @@ G1Xyzz unpack_xyzz(const uint32_t* p) {
 int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry& srs, const Fr* d_scalars, size_t m,
                 uint64_t* out_xy, uint8_t* out_inf) {
     ws.stream = stream;
-    if (!ws.host_wins) HIPCHK(hipHostMalloc((void**)&ws.host_wins, 64 * 192));
+    if (!ws.host_wins) HIPCHK(hipHostMalloc((void**)&ws.host_wins, HOST_WIN_POINTS * 192));
     uint32_t c, W;
     msm_shape(ctx, m, &c, &W);
     // fixed-base tables: every window reads its own pre-shifted copy of the base, so all windows share
@@ -560,7 +565,37 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         HIPCHK(hipMemcpyAsync(ws.host_wins + (size_t)slot * 48, cur, (size_t)nwin * 192, hipMemcpyDeviceToHost, s));
         return TYPLONK_OK;
     };
-    {
+    ws.rc = !ctx->msm_tree_reduce && c >= 3 && nsets <= 32;
+    if (ws.rc) {
+        RcShape& sh = ws.rcs;
+        sh.nsets = nsets;
+        sh.c1 = c - 1;
+        sh.cl = (c - 1 + 1) / 2;
+        sh.ch = c - 1 - sh.cl;
+        sh.lhc = std::min<uint32_t>(3, sh.ch);
+        sh.llc = std::min<uint32_t>(3, sh.cl);
+        sh.top_v = digit_v;
+        const uint64_t nrow = (uint64_t)nsets << (sh.c1 - sh.llc), ncol = (uint64_t)nsets << (sh.c1 - sh.lhc);
+        if ((rc = ensure(ctx, ws.part_a, ncol * 192))) return rc;
+        if ((rc = ensure(ctx, ws.part_b, nrow * 192))) return rc;
+        if ((rc = ensure(ctx, ws.rc_sums, (((uint64_t)nsets << sh.ch) + ((uint64_t)nsets << sh.cl)) * 192))) return rc;
+        if ((rc = ensure(ctx, ws.rc_bits, (uint64_t)nsets * 2 * RC_NB * 64 * 192))) return rc;
+        if ((rc = ensure(ctx, ws.rc_out, (uint64_t)nsets * 2 * RC_NB * 192))) return rc;
+        StageTimer st(ctx, "msm_reduce", s);
+        launch_msm_rc_reduce(buckets, sh, (uint32_t*)ws.part_b.p, (uint32_t*)ws.part_a.p, (uint32_t*)ws.rc_sums.p,
+                             (uint32_t*)ws.rc_bits.p, (uint32_t*)ws.rc_out.p, s);
+        if (nsets > 1) {
+            // plain MSM: per-set powers of two on the device, the host keeps its Horner over the windows
+            uint32_t* set_sums = (uint32_t*)ws.part_a.p;  // the column partials are consumed by now
+            launch_msm_rc_combine((const uint32_t*)ws.rc_out.p, sh, set_sums, s);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(ws.host_wins, set_sums, (size_t)nsets * 192, hipMemcpyDeviceToHost, s));
+            ws.rc = false;
+        } else {
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(ws.host_wins, ws.rc_out.p, (size_t)nsets * 2 * RC_NB * 192, hipMemcpyDeviceToHost, s));
+        }
+    } else {
         StageTimer st(ctx, "msm_reduce", s);
         if ((rc = reduce_group(0, B, nsets, digit_v, 0))) return rc;
     }
@@ -578,6 +613,31 @@ int msm_finish(typlonk_ctx* ctx, MsmWs& ws) {
     if (!ws.pending) return TYPLONK_OK;
     ws.pending = false;
     HIPCHK(hipStreamSynchronize(ws.stream));
+    if (ws.rc) {
+        // bit planes -> points by power of two: set j (offset c*j; 0 in table mode), rows carry 2^shift
+        const RcShape& sh = ws.rcs;
+        std::vector<G1Xyzz> pe(ws.c * sh.nsets + 2 * RC_NB + sh.cl + 2, G1Xyzz::inf());
+        int top = -1;
+        for (uint32_t j = 0; j < sh.nsets; ++j) {
+            uint32_t nbr, nbc, shift;
+            rc_bits(sh, j, &nbr, &nbc, &shift);
+            for (uint32_t kind = 0; kind < 2; ++kind)
+                for (uint32_t b = 0; b < (kind ? nbc : nbr); ++b) {
+                    const G1Xyzz pt = unpack_xyzz(ws.host_wins + (size_t)((j * 2 + kind) * RC_NB + b) * 48);
+                    if (pt.is_inf()) continue;
+                    const uint32_t e = ws.c * j + b + (kind ? 0u : shift);
+                    pe[e] = g1_add(pe[e], pt);
+                    top = std::max(top, (int)e);
+                }
+        }
+        G1Xyzz acc = G1Xyzz::inf();
+        for (int e = top; e >= 0; --e) {
+            if (!acc.is_inf()) acc = g1_dbl(acc);
+            if (!pe[e].is_inf()) acc = g1_add(acc, pe[e]);
+        }
+        write_affine_out(g1_to_affine(acc), ws.out_xy, ws.out_inf);
+        return TYPLONK_OK;
+    }
     G1Xyzz acc = G1Xyzz::inf();
     for (int j = (int)ws.W - 1; j >= 0; --j) {
         if (!acc.is_inf())
@@ -694,6 +754,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         if (c >= 4 && c <= 20) ctx->msm_c_override = c;
     }
     if (const char* e = getenv("TYPLONK_MSM_SORT")) ctx->msm_legacy_sort = (strcmp(e, "atomic") == 0);
+    if (const char* e = getenv("TYPLONK_MSM_REDUCE")) ctx->msm_tree_reduce = (strcmp(e, "running") == 0);
     *out = ctx;
     return TYPLONK_OK;
 }

@@ -88,6 +88,45 @@ void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uin
 void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
                        uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s);
 void launch_msm_fold(const uint32_t* in, uint32_t total, uint32_t group, uint32_t* out, hipStream_t s);
+
+// Row/column bucket reduction (msm_reduce.hip).  A bucket set of B = 2^c1 buckets is read as a grid of
+// R = 2^ch rows x C = 2^cl columns, k = hi * C + lo.  Every bucket weight splits as w(k) = wr(hi) + wc(lo):
+//   v <= cl : wr = hi << (cl - v),            wc = (lo >> v) + 1
+//   v >  cl : wr = (hi >> (v - cl)) + 1,      wc = 0
+// (v = virtual-copy bits of the set: top_v for the last set of a plain MSM, else 0), so
+// sum_k w(k) B_k = sum_hi wr(hi) Rsum_hi + sum_lo wc(lo) Csum_lo needs only PLAIN sums of buckets plus two
+// weighted sums of R + C points.  Those are returned as bit planes -- out[(set*2 + kind)*RC_NB + b] =
+// sum of the row (kind 0) / column (kind 1) sums whose weight has bit b set, rows WITHOUT their common
+// factor 2^shift -- and the host finishes with one Horner pass over powers of two.
+constexpr uint32_t RC_NB = 16;
+struct RcShape {
+    uint32_t nsets, c1, ch, cl;
+    uint32_t lhc, llc;  // log2 rows per column partial / columns per row partial
+    uint32_t top_v;
+};
+TY_HD uint32_t rc_set_v(const RcShape& sh, uint32_t set) { return set + 1 == sh.nsets ? sh.top_v : 0u; }
+// bits of the row / column weights of a set and the rows' common shift
+TY_HD void rc_bits(const RcShape& sh, uint32_t set, uint32_t* nbr, uint32_t* nbc, uint32_t* shift) {
+    const uint32_t v = rc_set_v(sh, set);
+    if (v <= sh.cl) {
+        *nbr = sh.ch;
+        *nbc = sh.cl - v + 1;
+        *shift = sh.cl - v;
+    } else {
+        const uint32_t d = v - sh.cl;
+        *nbr = (d <= sh.ch ? sh.ch - d : 0u) + 1;
+        *nbc = 0;
+        *shift = 0;
+    }
+}
+TY_HD uint32_t rc_weight(const RcShape& sh, uint32_t set, uint32_t kind, uint32_t idx) {
+    const uint32_t v = rc_set_v(sh, set);
+    if (v <= sh.cl) return kind == 0 ? idx : (idx >> v) + 1;
+    return kind == 0 ? (idx >> (v - sh.cl)) + 1 : 0u;
+}
+void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* pb, uint32_t* pa, uint32_t* sums,
+                          uint32_t* bitsum, uint32_t* out, hipStream_t s);
+void launch_msm_rc_combine(const uint32_t* planes, const RcShape& sh, uint32_t* set_sums, hipStream_t s);
 void launch_srs_generate(const Fr& s, uint64_t start, uint64_t n, uint32_t* pts, hipStream_t st);
 
 }  // namespace ty

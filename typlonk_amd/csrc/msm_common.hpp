@@ -8,10 +8,10 @@
 //   3. msm_scatter_kernel  counting sort of (point index, sign) by bucket.
 //   4. msm_accum_kernel    one thread per bucket: XYZZ accumulator in registers, mixed additions of
 //                          the bucket's affine points gathered from the resident SRS.
-//   5. msm_reduce_kernel   per window sum_k k*B_k: 8-bucket running sums per thread, offset by a
-//                          small scalar multiplication, then a wavefront __shfl_xor butterfly of
-//                          whole points; msm_fold_kernel repeats the butterfly until one point per
-//                          window is left.
+//   5. msm_rc_* kernels    per bucket set sum_k w(k)*B_k by the row/column split (launch.hpp): plain row
+//                          and column sums, then bit planes of the R + C weighted sums via wavefront
+//                          __shfl_xor butterflies of whole points.  (msm_reduce_kernel / msm_fold_kernel:
+//                          the first version, running sums + a small scalar multiplication per thread.)
 // The W window sums go to the host, which applies the 2^(c*j) weights (Horner) and normalises
 // to the canonical affine point.  Group addition is commutative and the result is canonical, so
 // the non-deterministic order inside a bucket (atomics in step 3) cannot change the output.

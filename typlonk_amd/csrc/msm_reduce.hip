@@ -73,6 +73,162 @@ __global__ __launch_bounds__(64) void msm_fold_kernel(const uint32_t* __restrict
 }
 
 
+// ---- row/column reduction (see launch.hpp) -------------------------------------------------------
+// 1. msm_rc_partial_kernel  two roles in one launch.  Row role: thread sums 2^llc consecutive buckets of
+//    one row.  Column role: thread sums the buckets of 2^lhc consecutive rows in one column (adjacent
+//    lanes = adjacent columns, so the loads coalesce) and stores hchunk-fastest so step 2 reads runs.
+// 2. msm_fold_seq_kernel    each thread sums 2^lseq consecutive partials, then a __shfl_xor butterfly
+//    over `lanes` lanes -> one row sum / column sum.
+// 3. msm_rc_bits_kernel     one wavefront per (set, kind, weight bit, 64-item chunk): butterfly sum of the
+//    items whose weight has that bit set.
+// 4. msm_rc_final_kernel    one wavefront per (set, kind, bit): sum over the chunks.
+__global__ __launch_bounds__(64) void msm_rc_partial_kernel(const uint32_t* __restrict__ buckets, RcShape sh,
+                                                            uint32_t nrow, uint32_t nrow_pad, uint32_t ncol,
+                                                            uint32_t* pb, uint32_t* pa) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t < nrow_pad) {
+        if (t >= nrow) return;
+        const uint64_t base = (uint64_t)t << sh.llc;
+        G1Xyzz v = ld_xyzz(buckets, base);
+        for (uint32_t l = 1; l < (1u << sh.llc); ++l) v = g1_add(v, ld_xyzz(buckets, base + l));
+        st_xyzz(pb, t, v);
+        return;
+    }
+    const uint32_t u = t - nrow_pad;
+    if (u >= ncol) return;
+    const uint32_t per_set = sh.c1 - sh.lhc;
+    const uint32_t set = u >> per_set, rem = u & ((1u << per_set) - 1);
+    const uint32_t lo = rem & ((1u << sh.cl) - 1), hchunk = rem >> sh.cl;
+    const uint64_t first = ((uint64_t)set << sh.c1) + ((uint64_t)(hchunk << sh.lhc) << sh.cl) + lo;
+    G1Xyzz v = ld_xyzz(buckets, first);
+    for (uint32_t h = 1; h < (1u << sh.lhc); ++h) v = g1_add(v, ld_xyzz(buckets, first + ((uint64_t)h << sh.cl)));
+    st_xyzz(pa, ((((uint64_t)set << sh.cl) + lo) << (sh.ch - sh.lhc)) + hchunk, v);
+}
+
+struct FoldSeg {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t threads, lseq, lanes;
+};
+__global__ __launch_bounds__(64) void msm_fold_seq_kernel(FoldSeg a, FoldSeg b, uint32_t blocks_a) {
+    const bool first = blockIdx.x < blocks_a;
+    const FoldSeg& g = first ? a : b;
+    const uint32_t t = (blockIdx.x - (first ? 0u : blocks_a)) * 64 + threadIdx.x;
+    G1Xyzz v = G1Xyzz::inf();
+    if (t < g.threads) {
+        const uint64_t base = (uint64_t)t << g.lseq;
+        v = ld_xyzz(g.in, base);
+        for (uint32_t i = 1; i < (1u << g.lseq); ++i) v = g1_add(v, ld_xyzz(g.in, base + i));
+    }
+    for (uint32_t mask = 1; mask < g.lanes; mask <<= 1) {
+        const G1Xyzz o = shfl_xor_point(v, (int)mask);
+        v = g1_add(v, o);
+    }
+    if (t < g.threads && (threadIdx.x & (g.lanes - 1)) == 0) st_xyzz(g.out, t / g.lanes, v);
+}
+
+// sums: row sums [set][hi] (nsets * R points) followed by column sums [set][lo]
+__global__ __launch_bounds__(64) void msm_rc_bits_kernel(const uint32_t* __restrict__ sums, RcShape sh, uint32_t rw,
+                                                         uint32_t cw, uint32_t* bitsum) {
+    const uint32_t nbr_max = sh.ch + 1, nbc_max = sh.cl + 1;
+    const uint32_t wps = nbr_max * rw + nbc_max * cw;
+    const uint32_t set = blockIdx.x / wps;
+    uint32_t r = blockIdx.x % wps, kind = 0, bit, chunk;
+    if (r < nbr_max * rw) {
+        bit = r / rw;
+        chunk = r % rw;
+    } else {
+        r -= nbr_max * rw;
+        kind = 1;
+        bit = r / cw;
+        chunk = r % cw;
+    }
+    uint32_t nbr, nbc, shift;
+    rc_bits(sh, set, &nbr, &nbc, &shift);
+    if (bit >= (kind ? nbc : nbr)) return;
+    const uint32_t idx = chunk * 64 + threadIdx.x;
+    const uint32_t n_items = kind ? (1u << sh.cl) : (1u << sh.ch);
+    G1Xyzz v = G1Xyzz::inf();
+    if (idx < n_items && ((rc_weight(sh, set, kind, idx) >> bit) & 1u)) {
+        const uint64_t at = kind ? ((uint64_t)sh.nsets << sh.ch) + ((uint64_t)set << sh.cl) + idx : ((uint64_t)set << sh.ch) + idx;
+        v = ld_xyzz(sums, at);
+    }
+    for (uint32_t mask = 1; mask < 64; mask <<= 1) {
+        const G1Xyzz o = shfl_xor_point(v, (int)mask);
+        v = g1_add(v, o);
+    }
+    if (threadIdx.x == 0) st_xyzz(bitsum, (uint64_t)((set * 2 + kind) * RC_NB + bit) * 64 + chunk, v);
+}
+
+__global__ __launch_bounds__(64) void msm_rc_final_kernel(const uint32_t* __restrict__ bitsum, RcShape sh, uint32_t rw,
+                                                          uint32_t cw, uint32_t* out) {
+    const uint32_t bit = blockIdx.x % RC_NB, kind = (blockIdx.x / RC_NB) & 1u, set = blockIdx.x / (2 * RC_NB);
+    uint32_t nbr, nbc, shift;
+    rc_bits(sh, set, &nbr, &nbc, &shift);
+    if (bit >= (kind ? nbc : nbr)) return;
+    const uint32_t count = kind ? cw : rw;
+    G1Xyzz v = G1Xyzz::inf();
+    if (threadIdx.x < count) v = ld_xyzz(bitsum, (uint64_t)blockIdx.x * 64 + threadIdx.x);
+    for (uint32_t mask = 1; mask < count; mask <<= 1) {
+        const G1Xyzz o = shfl_xor_point(v, (int)mask);
+        v = g1_add(v, o);
+    }
+    if (threadIdx.x == 0) st_xyzz(out, blockIdx.x, v);
+}
+
+// Plain (multi-set) MSMs: one wavefront per set applies the powers of two -- lane (kind, b) doubles its bit
+// plane b (+ shift for rows) times, then a butterfly sums the 2 * RC_NB lanes -> one point per set, so the
+// host's Horner over the windows stays c doublings + one addition per window.
+__global__ __launch_bounds__(64) void msm_rc_combine_kernel(const uint32_t* __restrict__ planes, RcShape sh,
+                                                            uint32_t* set_sums) {
+    const uint32_t set = blockIdx.x, kind = threadIdx.x / RC_NB, b = threadIdx.x % RC_NB;
+    uint32_t nbr, nbc, shift;
+    rc_bits(sh, set, &nbr, &nbc, &shift);
+    const bool valid = kind < 2 && b < (kind ? nbc : nbr);
+    G1Xyzz v = G1Xyzz::inf();
+    if (valid) v = ld_xyzz(planes, (uint64_t)(set * 2 + kind) * RC_NB + b);
+    const uint32_t e = valid ? b + (kind ? 0u : shift) : 0u;
+    const uint32_t emax = max(nbr ? nbr - 1 + shift : 0u, nbc ? nbc - 1 : 0u);
+    for (uint32_t i = 0; i < emax; ++i)
+        if (i < e) v = g1_dbl(v);
+    for (uint32_t mask = 1; mask < 2 * RC_NB; mask <<= 1) {
+        const G1Xyzz o = shfl_xor_point(v, (int)mask);
+        v = g1_add(v, o);
+    }
+    if (threadIdx.x == 0) st_xyzz(set_sums, set, v);
+}
+
+void launch_msm_rc_combine(const uint32_t* planes, const RcShape& sh, uint32_t* set_sums, hipStream_t s) {
+    hipLaunchKernelGGL(msm_rc_combine_kernel, dim3(sh.nsets), dim3(64), 0, s, planes, sh, set_sums);
+}
+
+void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* pb, uint32_t* pa, uint32_t* sums,
+                          uint32_t* bitsum, uint32_t* out, hipStream_t s) {
+    const uint32_t nrow = sh.nsets << (sh.c1 - sh.llc), ncol = sh.nsets << (sh.c1 - sh.lhc);
+    const uint32_t nrow_pad = (nrow + 63) & ~63u;
+    hipLaunchKernelGGL(msm_rc_partial_kernel, dim3((nrow_pad + ncol + 63) / 64), dim3(64), 0, s, buckets, sh, nrow, nrow_pad,
+                       ncol, pb, pa);
+    // row partials: 2^(cl - llc) per row; column partials: 2^(ch - lhc) per column
+    auto seg = [](const uint32_t* in, uint32_t* out, uint32_t n_in, uint32_t lcnt) {
+        FoldSeg g;
+        g.in = in;
+        g.out = out;
+        g.lseq = lcnt < 2 ? lcnt : 2;
+        g.lanes = 1u << (lcnt - g.lseq);
+        g.threads = n_in >> g.lseq;
+        return g;
+    };
+    uint32_t* rsum = sums;
+    uint32_t* csum = sums + ((uint64_t)sh.nsets << sh.ch) * 48;
+    const FoldSeg a = seg(pb, rsum, nrow, sh.cl - sh.llc), b = seg(pa, csum, ncol, sh.ch - sh.lhc);
+    const uint32_t ba = (a.threads + 63) / 64, bb = (b.threads + 63) / 64;
+    hipLaunchKernelGGL(msm_fold_seq_kernel, dim3(ba + bb), dim3(64), 0, s, a, b, ba);
+    const uint32_t rw = ((1u << sh.ch) + 63) / 64, cw = ((1u << sh.cl) + 63) / 64;
+    const uint32_t wps = (sh.ch + 1) * rw + (sh.cl + 1) * cw;
+    hipLaunchKernelGGL(msm_rc_bits_kernel, dim3(sh.nsets * wps), dim3(64), 0, s, sums, sh, rw, cw, bitsum);
+    hipLaunchKernelGGL(msm_rc_final_kernel, dim3(sh.nsets * 2 * RC_NB), dim3(64), 0, s, bitsum, sh, rw, cw, out);
+}
+
 void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
                        uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s) {
     hipLaunchKernelGGL(msm_reduce_kernel, dim3((nodes_total + 63) / 64), dim3(64), 0, s, buckets, B, L, nodes_total, group,
