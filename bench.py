@@ -294,7 +294,26 @@ def main() -> None:
                 "sample": f"first {ms} terms of the same scalar/SRS vectors, reference-faithful per-term "
                           f"double-and-add + affine normalisation + sum (kzg/src/lib.rs:41-54)",
                 "terms_per_s": ms / tc, "seconds": tc, "host_cpus": os.cpu_count()}
-            if not (parity_sample and parity_full):
+            # "fair CPU" (SURVEY 8d-ii): bucket method on all host cores (oracle_msm_pippenger) + the radix-2 NTT
+            mf = min(1 << 18, n)
+            scf = full[:mf].cpu().numpy().view(np.uint64)
+            xyf, inff = ctx.srs_download(sh.sid, 0, mf)
+            cf = max(4, min(16, mf.bit_length() - 4))
+            CO.msm_pippenger(scf[:1024], xyf[:1024], inff[:1024], c=8)      # spin the OpenMP team up
+            t1 = time.perf_counter()
+            f_xy, f_inf, f_ops, f_thr = CO.msm_pippenger(scf, xyf, inff, c=cf)
+            tf = time.perf_counter() - t1
+            gxy, ginf = ctx.msm_devptr(sh.sid, full.data_ptr(), mf)
+            parity_fair = bool((gxy == f_xy).all() and ginf == f_inf)
+            t1 = time.perf_counter()
+            CO.ntt(scf, mf.bit_length() - 1)
+            tn = time.perf_counter() - t1
+            result["parity"]["sample_vs_fair_cpu"] = parity_fair
+            result["cpu_fair"] = {
+                "kind": "port (bucket method, not the reference's algorithm)", "cores": f_thr, "window_bits": cf,
+                "sample": f"first {mf} terms", "seconds": tf, "terms_per_s": mf / tf, "value": f_ops / tf,
+                "unit": "G1-adds/s", "ntt_ms_1_thread": tn * 1e3, "ntt_log_n": mf.bit_length() - 1}
+            if not (parity_sample and parity_full and parity_fair):
                 result["value"] = None
                 result["error"] = "GPU result differs from the oracle: number withheld"
 

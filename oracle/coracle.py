@@ -47,6 +47,25 @@ def msm_reference(scalars, xy, inf=None):
     return out, int(oinf[0])
 
 
+def msm_pippenger(scalars, xy, inf=None, c: int = 13):
+    """bucket-method MSM on all host cores (the "fair CPU" baseline); returns (xy, inf, group_ops, threads)"""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 12)
+    m, n = scalars.shape[0], xy.shape[0]
+    out = np.zeros(12, dtype=np.uint64)
+    oinf = np.zeros(1, dtype=np.uint8)
+    infp = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        infp = _p8(inf)
+    ops, thr = C.c_uint64(), C.c_int()
+    rc = lib().oracle_msm_pippenger(_p64(scalars), _p64(xy), infp, C.c_size_t(m), C.c_size_t(n), C.c_uint32(c), _p64(out),
+                                    _p8(oinf), C.byref(ops), C.byref(thr))
+    if rc:
+        raise AssertionError(f"oracle_msm_pippenger failed: {rc}")
+    return out, int(oinf[0]), int(ops.value), int(thr.value)
+
+
 def srs_from_secret(s_mont, length):
     s = np.ascontiguousarray(s_mont, dtype=np.uint64).reshape(4)
     xy = np.zeros((length, 12), dtype=np.uint64)

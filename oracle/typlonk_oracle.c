@@ -29,6 +29,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef unsigned __int128 u128;
 
@@ -150,7 +153,7 @@ static void fr_inv(fr* r, const fr* a) {
 typedef struct { fq x, y, z; } g1j;      /* zero <=> z == 0 */
 typedef struct { fq x, y; int inf; } g1a;
 
-static uint64_t g_group_ops = 0; /* doublings + mixed adds executed (for the CPU baseline's G1-adds/s) */
+static _Thread_local uint64_t g_group_ops = 0; /* doublings + adds executed by this thread (for the CPU baselines' G1-adds/s) */
 uint64_t oracle_group_ops(void) { return g_group_ops; }
 void oracle_group_ops_reset(void) { g_group_ops = 0; }
 
@@ -216,6 +219,27 @@ static void g1a_mul(g1j* out, const g1a* base, const uint64_t k[RN]) {
 static void g1a_load(g1a* p, const uint64_t* xy, int inf) { memcpy(p->x.v, xy, 48); memcpy(p->y.v, xy + 6, 48); p->inf = inf; }
 static void g1a_store(uint64_t* xy, uint8_t* inf, const g1a* p) { memcpy(xy, p->x.v, 48); memcpy(xy + 6, p->y.v, 48); *inf = (uint8_t)p->inf; }
 
+/* general addition (add-2007-bl); not on the reference's path -- used by the bucket-method baseline below */
+static void g1j_add(g1j* p, const g1j* q) {
+    if (g1j_is_zero(q)) return;
+    if (g1j_is_zero(p)) { *p = *q; return; }
+    ++g_group_ops;
+    fq z1z1, z2z2, u1, u2, s1, s2, h, i, j, r, v, t;
+    fq_sqr(&z1z1, &p->z); fq_sqr(&z2z2, &q->z);
+    fq_mul(&u1, &p->x, &z2z2); fq_mul(&u2, &q->x, &z1z1);
+    fq_mul(&s1, &p->y, &q->z); fq_mul(&s1, &s1, &z2z2);
+    fq_mul(&s2, &q->y, &p->z); fq_mul(&s2, &s2, &z1z1);
+    if (fq_eq(&u1, &u2) && fq_eq(&s1, &s2)) { g1j_double(p); return; }
+    fq_sub(&h, &u2, &u1); fq_dbl(&i, &h); fq_sqr(&i, &i);
+    fq_mul(&j, &h, &i);
+    fq_sub(&r, &s2, &s1); fq_dbl(&r, &r);
+    fq_mul(&v, &u1, &i);
+    fq x3; fq_sqr(&x3, &r); fq_sub(&x3, &x3, &j); fq_dbl(&t, &v); fq_sub(&x3, &x3, &t);
+    fq y3; fq_sub(&t, &v, &x3); fq_mul(&y3, &r, &t); fq_mul(&t, &s1, &j); fq_dbl(&t, &t); fq_sub(&y3, &y3, &t);
+    fq z3; fq_add(&z3, &p->z, &q->z); fq_sqr(&z3, &z3); fq_sub(&z3, &z3, &z1z1); fq_sub(&z3, &z3, &z2z2); fq_mul(&z3, &z3, &h);
+    p->x = x3; p->y = y3; p->z = z3;
+}
+
 /* ================================================================ exported functions */
 
 /* evaluate_in_s, kzg/src/lib.rs:41-54.  Returns -1 for m > len (the assert! at :43). */
@@ -233,6 +257,67 @@ int oracle_msm_reference(const uint64_t* scalars, const uint64_t* points_xy, con
     }
     g1a res; g1j_to_affine(&res, &sum);
     g1a_store(out_xy, out_inf, &res);
+    return 0;
+}
+
+/* "Fair CPU" baseline: the same sum as oracle_msm_reference by the bucket method
+ * (unsigned c-bit windows, running-sum bucket reduction) on all cores (OpenMP).  NOT the reference's
+ * algorithm -- it exists so the GPU number can be held against a CPU doing the asymptotically right thing. */
+int oracle_msm_pippenger(const uint64_t* scalars, const uint64_t* points_xy, const uint8_t* points_inf, size_t m,
+                         size_t srs_len, uint32_t c, uint64_t out_xy[12], uint8_t* out_inf, uint64_t* group_ops_out,
+                         int* threads_out) {
+    if (m > srs_len) return -1;
+    if (c < 1 || c > 20) return -2;
+    const uint32_t W = (255 + c - 1) / c;
+    int T = 1;
+#ifdef _OPENMP
+    T = omp_get_max_threads();
+#endif
+    const int nchunks = (T + (int)W - 1) / (int)W;
+    const int ntasks = (int)W * nchunks;
+    uint64_t* canon = (uint64_t*)malloc((m ? m : 1) * 32);
+    g1j* partial = (g1j*)malloc(sizeof(g1j) * (size_t)ntasks);
+    uint64_t total_ops = 0;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)m; ++i) { fr s; memcpy(s.v, scalars + 4 * i, 32); fr_from_mont(canon + 4 * i, &s); }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int t = 0; t < ntasks; ++t) {
+        const uint32_t w = (uint32_t)(t / nchunks);
+        const size_t lo = m * (size_t)(t % nchunks) / (size_t)nchunks, hi = m * (size_t)(t % nchunks + 1) / (size_t)nchunks;
+        const uint64_t before = g_group_ops;
+        const size_t nb = ((size_t)1 << c) - 1;
+        g1j* bucket = (g1j*)malloc(sizeof(g1j) * nb);
+        for (size_t b = 0; b < nb; ++b) g1j_zero(&bucket[b]);
+        const uint32_t off = w * c;
+        for (size_t i = lo; i < hi; ++i) {
+            const uint64_t* k = canon + 4 * i;
+            uint64_t d = k[off / 64] >> (off % 64);
+            if (off % 64 + c > 64 && off / 64 + 1 < RN) d |= k[off / 64 + 1] << (64 - off % 64);
+            d &= ((uint64_t)1 << c) - 1;
+            if (!d) continue;
+            g1a base; g1a_load(&base, points_xy + 12 * i, points_inf ? points_inf[i] : 0);
+            g1j_add_mixed(&bucket[d - 1], &base);
+        }
+        g1j run, acc; g1j_zero(&run); g1j_zero(&acc);
+        for (size_t b = nb; b-- > 0;) { g1j_add(&run, &bucket[b]); g1j_add(&acc, &run); }
+        partial[t] = acc;
+        free(bucket);
+        const uint64_t delta = g_group_ops - before;
+#pragma omp atomic
+        total_ops += delta;
+    }
+    g1j sum; g1j_zero(&sum);
+    const uint64_t before = g_group_ops;
+    for (int w = (int)W - 1; w >= 0; --w) {
+        for (uint32_t d = 0; d < c; ++d) g1j_double(&sum);
+        for (int k = 0; k < nchunks; ++k) g1j_add(&sum, &partial[w * nchunks + k]);
+    }
+    total_ops += g_group_ops - before;
+    g1a res; g1j_to_affine(&res, &sum);
+    g1a_store(out_xy, out_inf, &res);
+    if (group_ops_out) *group_ops_out = total_ops;
+    if (threads_out) *threads_out = T;
+    free(partial); free(canon);
     return 0;
 }
 

@@ -72,6 +72,29 @@ def test_golden_msm_both_oracles():
             assert oi == 1 and not out[:6].any() and [int(x) for x in out[6:]] == O.fq_to_mont_limbs(1)
 
 
+def test_fair_cpu_pippenger_equals_reference_path():
+    """the bucket-method baseline (oracle_msm_pippenger, OpenMP) is the same function as evaluate_in_s: golden
+    vectors, every window width used, adversarial scalar sets (zeros, r - 1, repeated, short) and an infinity base"""
+    for case in load_golden("msm.json"):
+        srs = O.srs_from_secret_fast(int(case["secret"], 16), case["srs_len"])
+        sc = [int(x, 16) for x in case["scalars"]]
+        xy, inf = g1_pack(srs)
+        out, oi, ops, thr = CO.msm_pippenger(fr_pack(sc) if sc else np.zeros((0, 4), dtype=np.uint64), xy, inf, c=5)
+        assert g1_unpack_one(out, oi) == hex_pt(case["expected"])
+    xy, inf = CO.srs_from_secret(G(0x1234567), 300)
+    inf[17] = 1
+    sets = [O.random_frs(9, 300), [0] * 300, [O.R - 1] * 300, [7] * 300, [0, O.R - 1] * 150,
+            [i % 5 for i in range(300)], [1] + [0] * 299]
+    for sc in sets:
+        ref, ri = CO.msm_reference(fr_pack(sc), xy, inf)
+        for c in (1, 4, 13, 16):
+            out, oi, ops, thr = CO.msm_pippenger(fr_pack(sc), xy, inf, c=c)
+            assert (out == ref).all() and oi == ri, (c, sc[:3])
+            assert thr >= 1
+    with pytest.raises(AssertionError):
+        CO.msm_pippenger(fr_pack([1] * 301), xy, inf)
+
+
 def test_golden_ntt_both_oracles():
     assert [int(x, 16) for x in KAT["ntt4_1_2_3_4"]] == O.ntt([1, 2, 3, 4], 2) == fr_unpack(CO.ntt(fr_pack([1, 2, 3, 4]), 2))
     for case in load_golden("ntt.json"):
