@@ -68,6 +68,12 @@ int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
  * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point. */
 int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bits);
+/* Multi-GPU: declare that this entry holds bases [first_index, first_index + len) of a total_len-point SRS
+ * (one process per GPU, each with its own slice).  Every MSM / prover call on it then takes the FULL
+ * coefficient vector (pointer to coefficient 0, global length m <= total_len, same length check as
+ * kzg/src/lib.rs:43) and returns this rank's PARTIAL sum over its index range -- the identity if the range is
+ * empty.  The caller all-gathers the partial points and folds them (typlonk_g1_sum_host). */
+int typlonk_srs_set_shard(typlonk_ctx* ctx, uint32_t srs_id, size_t first_index, size_t total_len);
 int typlonk_srs_free(typlonk_ctx* ctx, uint32_t srs_id);
 int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
 

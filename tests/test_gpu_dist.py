@@ -47,3 +47,15 @@ def test_one_rank_through_rccl_all_gather():
     assert d["prove_valid"] is True
     for key in ("roofline", "cpu_baseline", "ms_per_step", "higher_is_better", "dtype", "data", "config"):
         assert key in d
+
+
+def test_two_ranks_sharded_prove_equals_single_rank():
+    """typlonk_srs_set_shard + ShardedProver: both proof shapes, every element, plus short MSMs whose range is
+    empty on one rank (tests/dist_prove_worker.py)"""
+    env = dict(os.environ, LOG_N="10")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_prove_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"sharded_prove_ok"')]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(lines[0])["sharded_prove_ok"] is True

@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RA
 # every symbol include/typlonk.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
-    "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_precompute", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
+    "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_precompute", "typlonk_srs_set_shard", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
     "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
     "typlonk_prover_round3", "typlonk_prover_round3_evals", "typlonk_prover_round4_batched", "typlonk_prover_free", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     lib.typlonk_srs_download.argtypes = [vp, C.c_uint32, C.c_size_t, C.c_size_t, u64p, u8p]
     lib.typlonk_srs_precompute.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.typlonk_srs_free.argtypes = [vp, C.c_uint32]
+    lib.typlonk_srs_set_shard.argtypes = [vp, C.c_uint32, C.c_size_t, C.c_size_t]
     lib.typlonk_srs_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
     lib.typlonk_msm_g1.argtypes = [vp, C.c_uint32, u64p, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_dev.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.c_size_t, u64p, u8p]
@@ -235,6 +236,11 @@ class Context:
         self._chk(self.lib.typlonk_srs_generate(self.h, _u64p(s), start, length, C.byref(sid)))
         return sid.value
 
+    def srs_set_shard(self, sid: int, first_index: int, total_len: int):
+        """this entry = bases [first_index, first_index + len) of a total_len-point SRS: MSM / prover calls on it
+        take the full coefficient vector and return this rank's partial sum"""
+        self._chk(self.lib.typlonk_srs_set_shard(self.h, sid, first_index, total_len))
+
     def srs_download(self, sid: int, offset: int = 0, count: int | None = None):
         count = self.srs_len(sid) - offset if count is None else count
         xy = np.zeros((count, 12), dtype=np.uint64)
@@ -348,12 +354,16 @@ class Context:
             cp = _u64p(cc)
         self._chk(self.lib.typlonk_lincomb_dev(self.h, ptrs, sc, k, cp, n, out.handle))
 
-    def prove(self, sid: int, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34, challenge_v=None):
+    def prove(self, sid: int, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34, challenge_v=None,
+              fold=None):
         """Three-round prover session.  challenge12(commitments) -> (beta, gamma) and
         challenge34(commitments + [Z]) -> (alpha, zeta) are callables returning 4-limb arrays (the
         caller's Fiat-Shamir).  Returns a dict of numpy arrays in the C-ABI form.
         challenge_v(evals) -> v selects the batched-opening shape (round3_evals + round4_batched):
-        "witness" then holds [W at zeta of a + v b + v^2 c + v^3 Z + v^4 r, W of Z at zeta*w]."""
+        "witness" then holds [W at zeta of a + v b + v^2 c + v^3 Z + v^4 r, W of Z at zeta*w].
+        fold(points) -> points combines per-rank partial commitments when `sid` is an SRS shard
+        (typlonk_srs_set_shard): one all-gather + fixed-order sum per round (typlonk_amd.dist.ShardedProver)."""
+        fold = fold or (lambda pts: pts)
         lib = self.lib
         w = (C.c_void_p * 3)(*[b.handle.value for b in wire_evals])
         pr = C.c_void_p()
@@ -362,7 +372,7 @@ class Context:
         self._chk(lib.typlonk_prover_round1(self.h, sid, circuit, w, pi_evals.handle if pi_evals is not None else None,
                                             C.byref(pr), C.byref(cxy), C.byref(cinf)))
         try:
-            commits = [(np.array(cxy[i], dtype=np.uint64), int(cinf[i])) for i in range(3)]
+            commits = fold([(np.array(cxy[i], dtype=np.uint64), int(cinf[i])) for i in range(3)])
             beta, gamma = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in challenge12(commits)]
             ks = ((C.c_uint64 * 4) * 3)()
             for i in range(3):
@@ -371,30 +381,32 @@ class Context:
             zxy = np.zeros(12, dtype=np.uint64)
             zinf = np.zeros(1, dtype=np.uint8)
             self._chk(lib.typlonk_prover_round2(pr, _u64p(beta), _u64p(gamma), C.byref(ks), _u64p(zxy), _u8p(zinf)))
+            (zxy, zi), = fold([(zxy, int(zinf[0]))])
+            zinf[0] = zi
             alpha, zeta = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
                            for x in challenge34(commits + [(zxy, int(zinf[0]))])]
             if challenge_v is not None:
                 pe = ProofEvals()
                 self._chk(lib.typlonk_prover_round3_evals(pr, _u64p(alpha), _u64p(zeta), C.byref(pe)))
                 evals = [np.array(pe.evals[i], dtype=np.uint64) for i in range(6)]
+                t_commit = fold([(np.array(pe.t_xy[i], dtype=np.uint64), int(pe.t_inf[i])) for i in range(3)])
                 v = np.ascontiguousarray(challenge_v(evals), dtype=np.uint64).reshape(4)
                 wxy = ((C.c_uint64 * 12) * 2)()
                 winf = (C.c_uint8 * 2)()
                 self._chk(lib.typlonk_prover_round4_batched(pr, _u64p(v), C.byref(wxy), C.byref(winf)))
                 return {
-                    "commit": commits, "z_commit": (zxy, int(zinf[0])),
-                    "t_commit": [(np.array(pe.t_xy[i], dtype=np.uint64), int(pe.t_inf[i])) for i in range(3)],
-                    "witness": [(np.array(wxy[i], dtype=np.uint64), int(winf[i])) for i in range(2)],
+                    "commit": commits, "z_commit": (zxy, int(zinf[0])), "t_commit": t_commit,
+                    "witness": fold([(np.array(wxy[i], dtype=np.uint64), int(winf[i])) for i in range(2)]),
                     "evals": evals, "batched": True,
                 }
             tail = ProofTail()
             self._chk(lib.typlonk_prover_round3(pr, _u64p(alpha), _u64p(zeta), C.byref(tail)))
         finally:
             lib.typlonk_prover_free(pr)
+        tw = fold([(np.array(tail.t_xy[i], dtype=np.uint64), int(tail.t_inf[i])) for i in range(3)] +
+                  [(np.array(tail.w_xy[i], dtype=np.uint64), int(tail.w_inf[i])) for i in range(6)])
         return {
-            "commit": commits, "z_commit": (zxy, int(zinf[0])),
-            "t_commit": [(np.array(tail.t_xy[i], dtype=np.uint64), int(tail.t_inf[i])) for i in range(3)],
-            "witness": [(np.array(tail.w_xy[i], dtype=np.uint64), int(tail.w_inf[i])) for i in range(6)],
+            "commit": commits, "z_commit": (zxy, int(zinf[0])), "t_commit": tw[:3], "witness": tw[3:],
             "evals": [np.array(tail.evals[i], dtype=np.uint64) for i in range(6)],
         }
 

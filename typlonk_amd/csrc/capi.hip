@@ -28,6 +28,15 @@ struct SrsEntry {
     uint32_t* d_points = nullptr;  // len * PT_WORDS u32 (96 B payload on a 128-B stride), identity = (0,0)
     size_t len = 0;
     uint32_t table_c = 0, table_T = 0;  // fixed-base tables 2^(c t) P_i at index t*len + i (typlonk_srs_precompute)
+    // typlonk_srs_set_shard: this entry holds bases [shard_first, shard_first + len) of a total_len-point SRS
+    size_t shard_first = 0, total_len = 0;
+    size_t total() const { return total_len ? total_len : len; }
+    // part [off, off + ml) of an m-term MSM that falls into this entry
+    void local_range(size_t m, size_t* off, size_t* ml) const {
+        const size_t lo = std::min(shard_first, m), hi = std::min(shard_first + len, m);
+        *off = lo;
+        *ml = hi - lo;
+    }
 };
 
 struct Table {
@@ -651,24 +660,30 @@ int msm_finish(typlonk_ctx* ctx, MsmWs& ws) {
 int msm_validate(typlonk_ctx* ctx, uint32_t srs_id, size_t m, const SrsEntry** srs) {
     auto it = ctx->srs.find(srs_id);
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
-    if (m > it->second.len) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
+    if (m > it->second.total()) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
     *srs = &it->second;
     return TYPLONK_OK;
 }
 
+// d_scalars points at coefficient 0 of the m-term vector (ptr_is_local: at the first coefficient of this
+// entry's share instead); an SRS shard sums only its own index range
 int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12],
-            uint8_t* out_inf) {
+            uint8_t* out_inf, bool ptr_is_local = false) {
     if (!out_xy || !out_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
     const SrsEntry* srs = nullptr;
     int rc = msm_validate(ctx, srs_id, m, &srs);
     if (rc) return rc;
     prof_begin(ctx);
-    if (m == 0) {
+    size_t off, ml;
+    srs->local_range(m, &off, &ml);
+    if (ml == 0) {
         write_affine_out(G1Affine::inf(), out_xy, out_inf);
         prof_collect(ctx);
         return TYPLONK_OK;
     }
     if (!d_scalars) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null scalars");
+    if (!ptr_is_local) d_scalars += off;
+    m = ml;
     if ((rc = msm_enqueue(ctx, ctx->ws[0], ctx->stream, *srs, d_scalars, m, out_xy, out_inf))) return rc;
     if ((rc = msm_finish(ctx, ctx->ws[0]))) return rc;
     prof_collect(ctx);
@@ -699,11 +714,13 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
     for (size_t k = 0; k < count && !rc; ++k) {
         MsmWs& ws = ctx->ws[k & 1];
         if ((rc = msm_finish(ctx, ws))) break;
-        if (m[k] == 0) {
+        size_t off, ml;
+        srs->local_range(m[k], &off, &ml);
+        if (ml == 0) {
             write_affine_out(G1Affine::inf(), out_xy + 12 * k, out_inf + k);
             continue;
         }
-        rc = msm_enqueue(ctx, ws, (k & 1) ? ctx->stream2 : ctx->stream, *srs, (const Fr*)d_scalars[k], m[k],
+        rc = msm_enqueue(ctx, ws, (k & 1) ? ctx->stream2 : ctx->stream, *srs, (const Fr*)d_scalars[k] + off, ml,
                          out_xy + 12 * k, out_inf + k);
     }
     int r0 = msm_finish(ctx, ctx->ws[0]);
@@ -831,6 +848,17 @@ int typlonk_srs_free(typlonk_ctx* ctx, uint32_t srs_id) {
     return TYPLONK_OK;
 }
 
+int typlonk_srs_set_shard(typlonk_ctx* ctx, uint32_t srs_id, size_t first_index, size_t total_len) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    auto it = ctx->srs.find(srs_id);
+    if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
+    if (first_index > total_len || it->second.len > total_len - first_index)
+        return fail(ctx, TYPLONK_ERR_RANGE, "shard does not fit into total_len");
+    it->second.shard_first = first_index;
+    it->second.total_len = total_len;
+    return TYPLONK_OK;
+}
+
 int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len) {
     if (!ctx || !len) return TYPLONK_ERR_INVALID_ARG;
     auto it = ctx->srs.find(srs_id);
@@ -933,13 +961,15 @@ int typlonk_msm_g1(typlonk_ctx* ctx, uint32_t srs_id, const uint64_t* scalars, s
     // validate the length before touching the device so the error matches the reference's assert
     auto it = ctx->srs.find(srs_id);
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
-    if (m > it->second.len) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
-    if (m) {
-        int rc = ensure(ctx, ctx->scal, m * sizeof(Fr));
+    if (m > it->second.total()) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
+    size_t off, ml;
+    it->second.local_range(m, &off, &ml);
+    if (ml) {  // only this entry's share of the coefficients crosses PCIe
+        int rc = ensure(ctx, ctx->scal, ml * sizeof(Fr));
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->scal.p, scalars, m * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->scal.p, scalars + 4 * off, ml * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     }
-    return msm_run(ctx, srs_id, (const Fr*)ctx->scal.p, m, out_xy, out_inf);
+    return msm_run(ctx, srs_id, (const Fr*)ctx->scal.p, m, out_xy, out_inf, /*ptr_is_local=*/true);
 }
 
 int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift) {

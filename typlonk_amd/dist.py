@@ -48,6 +48,21 @@ def allgather_fold(partial_xy: np.ndarray, partial_inf: int, device: torch.devic
     return g1_sum_host(allrec[:, :12].copy(), allrec[:, 12].astype(np.uint8))
 
 
+def allgather_fold_many(points, device: torch.device, group=None):
+    """the same for k points at once (one collective per prover round): points = [(xy[12], inf), ...]"""
+    world = dist.get_world_size(group)
+    k = len(points)
+    rec = np.zeros((k, 13), dtype=np.uint64)
+    for i, (xy, inf) in enumerate(points):
+        rec[i, :12] = np.asarray(xy, dtype=np.uint64).reshape(12)
+        rec[i, 12] = inf
+    mine = torch.from_numpy(rec.view(np.int64).copy()).to(device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    allrec = torch.stack(out).cpu().numpy().view(np.uint64)      # (world, k, 13)
+    return [g1_sum_host(allrec[:, i, :12].copy(), allrec[:, i, 12].astype(np.uint8)) for i in range(k)]
+
+
 class ShardedMsm:
     """SRS shard resident on this rank's GPU + the collective combine."""
 
@@ -63,22 +78,44 @@ class ShardedMsm:
     def generate_srs(self, secret_limbs):
         """build only this rank's slice [s^lo G, ..., s^(hi-1) G] in HBM"""
         self.sid = self.ctx.srs_generate(secret_limbs, self.hi - self.lo, start=self.lo)
+        self.ctx.srs_set_shard(self.sid, self.lo, self.total_len)
         return self.sid
 
     def load_srs(self, xy_full, inf_full=None):
         xy = np.asarray(xy_full, dtype=np.uint64).reshape(-1, 12)[self.lo:self.hi]
         inf = None if inf_full is None else np.asarray(inf_full, dtype=np.uint8)[self.lo:self.hi]
         self.sid = self.ctx.srs_load(xy, inf)
+        self.ctx.srs_set_shard(self.sid, self.lo, self.total_len)
         return self.sid
 
-    def msm_local_devptr(self, d_scalars_local: int, m_local: int):
-        """partial sum over this rank's slice; scalars for [lo, lo+m_local) already in HBM"""
-        return self.ctx.msm_devptr(self.sid, d_scalars_local, m_local)
+    def msm_local_devptr(self, d_scalars: int, m: int):
+        """this rank's partial sum of an m-term MSM; d_scalars = device address of coefficient 0 of the full
+        vector (a rank holding only its slice passes slice_address - 32 * lo; nothing outside the slice is read)"""
+        return self.ctx.msm_devptr(self.sid, d_scalars, m)
 
-    def msm_devptr(self, d_scalars_local: int, m: int):
+    def msm_devptr(self, d_scalars: int, m: int):
         """full m-term MSM result on every rank"""
-        lo, hi = local_range(m, self.total_len, self.world, self.rank)
-        xy, inf = self.msm_local_devptr(d_scalars_local, hi - lo)
+        xy, inf = self.msm_local_devptr(d_scalars, m)
         if self.world == 1 and not self.force_collective:
             return xy, inf
         return allgather_fold(xy, inf, self.device, self.group)
+
+    def fold(self, points):
+        if self.world == 1 and not self.force_collective:
+            return points
+        return allgather_fold_many(points, self.device, self.group)
+
+
+class ShardedProver:
+    """prove() with every MSM index-sharded over the ranks (BASELINE configs 4-5: "MSM sharded across 8 x MI355X",
+    "the NTT runs single-GPU").  Every rank runs the same prover session on the same witness -- NTTs, grand
+    product and quotient are replicated, which costs no communication -- but commits only over its SRS shard;
+    the partial commitments of a round are all-gathered and summed in rank order, so every rank feeds identical
+    points to its Fiat-Shamir transcript and ends with the identical proof."""
+
+    def __init__(self, sharded: ShardedMsm):
+        self.sh = sharded
+
+    def prove(self, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34, challenge_v=None):
+        return self.sh.ctx.prove(self.sh.sid, circuit, wire_evals, pi_evals, cosets, challenge12, challenge34,
+                                 challenge_v=challenge_v, fold=self.sh.fold)
