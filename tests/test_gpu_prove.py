@@ -272,3 +272,38 @@ def test_readme_pythagorean_circuit(ctx):
     assert fr(bad["evals"][5]) != 0
     ctx.circuit_free(cid)
     ctx.srs_free(sid)
+
+
+def test_gpu_proof_passes_the_reference_verifier_with_real_pairings(ctx):
+    """End to end: the proof typlonk_prover_round1/2/3 produces for the squaring chain (n = 32) is accepted by the
+    restated plonk::proof::verify (oracle/pairing.py: 12 pairings, linearisation commitment built from the GPU's
+    own selector / sigma commitments); a tampered evaluation or witness is rejected"""
+    from oracle import pairing as PR
+
+    log_n = 5
+    n, cols, q_evals, perm, cid = _setup(ctx, log_n)
+    secret = 0x5EC2E7D00D
+    sid = ctx.srs_generate(_limbs(secret), n + 3)
+    got = _gpu_prove(ctx, sid, cid, cols, n)
+    pt = lambda t: g1_unpack_one(t[0], t[1])                   # noqa: E731
+    fr = lambda a: O.fr_from_mont_limbs([int(v) for v in a])   # noqa: E731
+    ev = [fr(e) for e in got["evals"]]
+    wit = [pt(w) for w in got["witness"]]
+    proof = {"commit": [pt(c) for c in got["commit"]], "open": [(wit[i], ev[i]) for i in range(3)],
+             "z_commit": pt(got["z_commit"]), "z_open": (wit[3], ev[3]), "zw_open": (wit[4], ev[4]),
+             "t_commit": [pt(c) for c in got["t_commit"]], "r_open": (wit[5], ev[5])}
+    _, sig = PO.compile_permutation(perm, n, log_n)
+    sigma_polys = [O.interpolate(s, log_n) for s in sig]
+    gpu_commit = lambda cf: pt(ctx.msm(sid, fr_pack(cf) if cf else np.zeros((0, 4), dtype=np.uint64)))   # noqa: E731
+    fixed = [gpu_commit(O.interpolate(q_evals[k], log_n)) for k in ("q_l", "q_r", "q_o", "q_m", "q_c")]
+    sigma_c = [gpu_commit(p) for p in sigma_polys]
+    g2, g2s = PR.srs_g2(secret)
+    alpha, beta, gamma = CH
+    args = (fixed, sigma_polys, sigma_c, PO.COSETS, [0] * n, (alpha, beta, gamma), ZETA, g2, g2s)
+    assert PR.plonk_verify(log_n, proof, *args)
+    bad = dict(proof, open=[(wit[0], (ev[0] + 1) % O.R)] + proof["open"][1:])
+    assert not PR.plonk_verify(log_n, bad, *args)
+    bad = dict(proof, r_open=(O.g1_add(wit[5], O.G1), ev[5]))
+    assert not PR.plonk_verify(log_n, bad, *args)
+    ctx.circuit_free(cid)
+    ctx.srs_free(sid)

@@ -185,3 +185,55 @@ def test_readme_circuit_oracle():
     _, bad, _, _ = PO.pythagorean_circuit([3, 4, 6])
     pb = PO.prove(log_n, bad, q, perm, [0] * n, (11, 22, 33), 44, lambda p: O.msm_naive(p, srs))
     assert pb["rem"] != [] or pb["r_open"][1] != 0
+
+
+# ---- pairing + the reference's verifiers (oracle/pairing.py) ----------------------------------------------
+def test_pairing_is_a_pairing():
+    from oracle import pairing as PR
+    assert PR.g2_is_on_curve(PR.G2) and PR.g2_mul(PR.G2, O.R - 1) == PR.g2_neg(PR.G2)
+    e = PR.pairing(O.G1, PR.G2)
+    one = PR.f12_one()
+    assert e != one and PR.f12_pow(e, O.R) == one
+    a, b = 0x1234567, 0xFEDCBA987
+    assert PR.pairing(O.g1_mul(O.G1, a), PR.g2_mul(PR.G2, b)) == PR.f12_pow(e, a * b % O.R)
+    assert PR.pairing(None, PR.G2) == one and PR.pairing(O.G1, None) == one
+
+
+def test_reference_commit_test_with_the_real_verify():
+    """kzg/src/lib.rs:95-109 in full: commit(1 + 2X + 3X^2) with s = 2, open at 1, verify -- and a wrong value fails"""
+    from oracle import pairing as PR
+    srs = O.srs_from_secret(2, 10)
+    g2, g2s = PR.srs_g2(2)
+    c = O.kzg_commit(srs, [1, 2, 3])
+    w, y = O.kzg_open(srs, [1, 2, 3], 1)
+    assert c == hex_pt(KAT["commit_1_2_3_s2"]) and y == 6
+    assert PR.kzg_verify(c, (w, y), 1, g2, g2s)
+    assert not PR.kzg_verify(c, (w, 7), 1, g2, g2s)
+    assert not PR.kzg_verify(c, (w, y), 2, g2, g2s)
+
+
+def _cpu_prove_verify(inputs):
+    from oracle import pairing as PR
+    from oracle import plonk_oracle as PO
+    log_n, cols, q_evals, perm = PO.pythagorean_circuit(inputs)
+    n = 1 << log_n
+    secret = 0xC0FFEE
+    srs = O.srs_from_secret_fast(secret, n + 3)
+    commit = lambda p: O.kzg_commit(srs, p) if p else None      # noqa: E731
+    ch, zeta = (0x1234567DEADBEEF, 0xABCDEF0123456789ABCDEF, 0x55AA55AA77), 0x0F1E2D3C4B5A69788796A5B4C3D2E1F0
+    proof = PO.prove(log_n, cols, q_evals, perm, [0] * n, ch, zeta, commit)
+    _, sig = PO.compile_permutation(perm, n, log_n)
+    sigma_polys = [O.interpolate(s_, log_n) for s_ in sig]
+    fixed = [commit(O.interpolate(q_evals[k], log_n)) for k in ("q_l", "q_r", "q_o", "q_m", "q_c")]
+    g2, g2s = PR.srs_g2(secret)
+    ok = PR.plonk_verify(log_n, proof, fixed, sigma_polys, [commit(p) for p in sigma_polys], PO.COSETS, [0] * n, ch, zeta,
+                         g2, g2s)
+    return ok, proof
+
+
+def test_readme_circuit_prove_and_verify_on_cpu():
+    """BASELINE config 1 / plonk/src/builder/test.rs:25-37: [3,4,5] proves and verifies, [3,4,6] does not"""
+    ok, proof = _cpu_prove_verify([3, 4, 5])
+    assert ok and proof["r_open"][1] == 0
+    bad, _ = _cpu_prove_verify([3, 4, 6])
+    assert not bad
