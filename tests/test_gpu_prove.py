@@ -307,3 +307,38 @@ def test_gpu_proof_passes_the_reference_verifier_with_real_pairings(ctx):
     assert not PR.plonk_verify(log_n, bad, *args)
     ctx.circuit_free(cid)
     ctx.srs_free(sid)
+
+
+def test_prove_with_the_transcript_and_verify_by_recomputing_challenges(ctx):
+    """prove() without injected challenges uses typlonk_amd/transcript.py (the reference's ChallengeGenerator); the
+    verifier side recomputes them from the commitments as verify_challenges does (proof.rs:236-246)"""
+    from oracle import pairing as PR
+    from typlonk_amd import transcript as T
+
+    log_n = 4
+    n, cols, q_evals, perm, cid = _setup(ctx, log_n)
+    secret = 0x77AA55
+    sid = ctx.srs_generate(_limbs(secret), n + 3)
+    wires = [_up(ctx, c, n) for c in cols]
+    got = ctx.prove(sid, cid, wires, None, [_limbs(k) for k in PO.COSETS])
+    pt = lambda t: g1_unpack_one(t[0], t[1])                   # noqa: E731
+    fr = lambda a: O.fr_from_mont_limbs([int(v) for v in a])   # noqa: E731
+    beta, gamma = [fr(x) for x in T.challenge12(got["commit"])]
+    alpha, zeta = [fr(x) for x in T.challenge34(got["commit"] + [got["z_commit"]])]
+    ev = [fr(e) for e in got["evals"]]
+    wit = [pt(w) for w in got["witness"]]
+    assert ev[5] == 0
+    proof = {"commit": [pt(c) for c in got["commit"]], "open": [(wit[i], ev[i]) for i in range(3)],
+             "z_commit": pt(got["z_commit"]), "z_open": (wit[3], ev[3]), "zw_open": (wit[4], ev[4]),
+             "t_commit": [pt(c) for c in got["t_commit"]], "r_open": (wit[5], ev[5])}
+    _, sig = PO.compile_permutation(perm, n, log_n)
+    sigma_polys = [O.interpolate(s, log_n) for s in sig]
+    gpu_commit = lambda cf: pt(ctx.msm(sid, fr_pack(cf) if cf else np.zeros((0, 4), dtype=np.uint64)))   # noqa: E731
+    fixed = [gpu_commit(O.interpolate(q_evals[k], log_n)) for k in ("q_l", "q_r", "q_o", "q_m", "q_c")]
+    g2, g2s = PR.srs_g2(secret)
+    assert PR.plonk_verify(log_n, proof, fixed, sigma_polys, [gpu_commit(p) for p in sigma_polys], PO.COSETS, [0] * n,
+                           (alpha, beta, gamma), zeta, g2, g2s)
+    for b in wires:
+        b.free()
+    ctx.circuit_free(cid)
+    ctx.srs_free(sid)

@@ -186,3 +186,33 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
                     src = open(os.path.join(dirpath, f)).read()
                     assert not pat.search(src), f"{f} references the oracle"
+
+
+# ---- Fiat-Shamir transcript (typlonk_amd/transcript.py; unverifiable against Rust here, see its docstring) -------
+def test_transcript_building_blocks():
+    import struct
+
+    from typlonk_amd import transcript as T
+
+    # ChaCha block function against RFC 7539 section 2.3.2 (20 rounds; the reference's StdRng runs 12)
+    key = list(struct.unpack("<8I", bytes(range(32))))
+    out = T.chacha_block(key, 0, rounds=20, state_tail=[1, 0x09000000, 0x4A000000, 0])
+    assert out == [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3, 0xC7F4D1C7, 0x0368C033, 0x9AAA2204, 0x4E6CD4C3,
+                   0x466482D2, 0x09AA9F07, 0x05D7C214, 0xA2028BD9, 0xD19C12B5, 0xB94E16DE, 0xE883D0CB, 0x4E3C50A2]
+    # serialize_unchecked: canonical little-endian x || y, infinity flag 0x40 on the last byte, identity = (0, 1)
+    gx = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
+    gy = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+    mont = lambda v: [(v * (1 << 384) % T.FQ_MODULUS >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]   # noqa: E731
+    b = T.serialize_unchecked_g1(mont(gx) + mont(gy), 0)
+    assert b == gx.to_bytes(48, "little") + gy.to_bytes(48, "little")
+    z = T.serialize_unchecked_g1([0] * 12, 1)
+    assert z[:48] == bytes(48) and z[48] == 1 and z[-1] == 0x40 and z[49:95] == bytes(46)
+    # challenges: deterministic, < r, different transcripts give different challenges, 4-limb C-ABI form
+    a = T.challenge12([(mont(gx) + mont(gy), 0)] * 3)
+    a2 = T.challenge12([(mont(gx) + mont(gy), 0)] * 3)
+    c = T.challenge34([(mont(gx) + mont(gy), 0)] * 3 + [([0] * 12, 1)])
+    val = lambda l: sum(int(x) << (64 * i) for i, x in enumerate(l))   # noqa: E731
+    assert all((x == y).all() for x, y in zip(a, a2)) and len(a) == 2 and len(c) == 2
+    assert all(val(x) < T.FR_MODULUS for x in a + c) and val(a[0]) != val(c[0]) and val(a[0]) != val(a[1])
+    # seed expansion: 32 bytes, a function of the seed
+    assert len(T.seed_from_u64(0)) == 32 and T.seed_from_u64(0) != T.seed_from_u64(1)

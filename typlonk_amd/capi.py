@@ -354,8 +354,8 @@ class Context:
             cp = _u64p(cc)
         self._chk(self.lib.typlonk_lincomb_dev(self.h, ptrs, sc, k, cp, n, out.handle))
 
-    def prove(self, sid: int, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34, challenge_v=None,
-              fold=None):
+    def prove(self, sid: int, circuit: int, wire_evals, pi_evals, cosets, challenge12=None, challenge34=None,
+              challenge_v=None, fold=None):
         """Three-round prover session.  challenge12(commitments) -> (beta, gamma) and
         challenge34(commitments + [Z]) -> (alpha, zeta) are callables returning 4-limb arrays (the
         caller's Fiat-Shamir).  Returns a dict of numpy arrays in the C-ABI form.
@@ -364,6 +364,11 @@ class Context:
         fold(points) -> points combines per-rank partial commitments when `sid` is an SRS shard
         (typlonk_srs_set_shard): one all-gather + fixed-order sum per round (typlonk_amd.dist.ShardedProver)."""
         fold = fold or (lambda pts: pts)
+        if challenge12 is None or challenge34 is None:
+            # the reference's own Fiat-Shamir (plonk/src/proof/challenges.rs), see typlonk_amd/transcript.py
+            from . import transcript as _t
+            challenge12 = challenge12 or _t.challenge12
+            challenge34 = challenge34 or _t.challenge34
         lib = self.lib
         w = (C.c_void_p * 3)(*[b.handle.value for b in wire_evals])
         pr = C.c_void_p()
