@@ -97,8 +97,10 @@ struct typlonk_ctx {
     uint32_t next_circuit = 1;
     // MSM
     DevBuf scal;
-    MsmWs ws[2];
-    hipStream_t stream2 = nullptr;  // second lane of typlonk_msm_g1_batch*
+    static constexpr int MSM_LANES = 4;
+    MsmWs ws[MSM_LANES];
+    hipStream_t lane[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // lanes 1.. of typlonk_msm_g1_batch* (lane 0 = stream)
+    int msm_inflight = 4;           // MSMs of a batch in flight at once (TYPLONK_MSM_INFLIGHT, 1..MSM_LANES)
     hipEvent_t batch_evt = nullptr;
     // NTT
     DevBuf ntt_scratch, ntt_io, quot_ext, ops_tmp, prover_mem;
@@ -704,15 +706,19 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
     prof_begin(ctx);
     const bool prof = ctx->profiling;
     ctx->profiling = false;  // stage events are per-call; a batch interleaves two calls
-    if (!ctx->stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    const int lanes = std::max(1, std::min<int>(ctx->msm_inflight, typlonk_ctx::MSM_LANES));
     if (!ctx->batch_evt) HIPCHK(hipEventCreateWithFlags(&ctx->batch_evt, hipEventDisableTiming));
     // work already queued on the context's stream (e.g. the iNTT that produced the scalars) must be
-    // visible to the second lane
+    // visible to the other lanes
     HIPCHK(hipEventRecord(ctx->batch_evt, ctx->stream));
-    HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->batch_evt, 0));
+    for (int l = 1; l < lanes; ++l) {
+        if (!ctx->lane[l]) HIPCHK(hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
+        HIPCHK(hipStreamWaitEvent(ctx->lane[l], ctx->batch_evt, 0));
+    }
     int rc = TYPLONK_OK;
     for (size_t k = 0; k < count && !rc; ++k) {
-        MsmWs& ws = ctx->ws[k & 1];
+        const int l = (int)(k % lanes);
+        MsmWs& ws = ctx->ws[l];
         if ((rc = msm_finish(ctx, ws))) break;
         size_t off, ml;
         srs->local_range(m[k], &off, &ml);
@@ -720,13 +726,15 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
             write_affine_out(G1Affine::inf(), out_xy + 12 * k, out_inf + k);
             continue;
         }
-        rc = msm_enqueue(ctx, ws, (k & 1) ? ctx->stream2 : ctx->stream, *srs, (const Fr*)d_scalars[k] + off, ml,
+        rc = msm_enqueue(ctx, ws, l ? ctx->lane[l] : ctx->stream, *srs, (const Fr*)d_scalars[k] + off, ml,
                          out_xy + 12 * k, out_inf + k);
     }
-    int r0 = msm_finish(ctx, ctx->ws[0]);
-    int r1 = msm_finish(ctx, ctx->ws[1]);
+    for (int l = 0; l < typlonk_ctx::MSM_LANES; ++l) {
+        const int r = msm_finish(ctx, ctx->ws[l]);
+        if (!rc) rc = r;
+    }
     ctx->profiling = prof;
-    return rc ? rc : (r0 ? r0 : r1);
+    return rc;
 }
 
 }  // namespace
@@ -772,6 +780,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     }
     if (const char* e = getenv("TYPLONK_MSM_SORT")) ctx->msm_legacy_sort = (strcmp(e, "atomic") == 0);
     if (const char* e = getenv("TYPLONK_MSM_REDUCE")) ctx->msm_tree_reduce = (strcmp(e, "running") == 0);
+    if (const char* e = getenv("TYPLONK_MSM_INFLIGHT")) ctx->msm_inflight = atoi(e);
     *out = ctx;
     return TYPLONK_OK;
 }
@@ -791,11 +800,13 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (DevBuf* b : {&ws.keys, &ws.sorted, &ws.counts, &ws.offsets, &ws.cursor, &ws.blocksums, &ws.buckets, &ws.part_a,
-                          &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base, &ws.heavy, &ws.tasks, &ws.hpart})
+                          &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base, &ws.heavy, &ws.tasks, &ws.hpart,
+                          &ws.rc_sums, &ws.rc_bits, &ws.rc_out})
             release(*b);
         if (ws.host_wins) (void)hipHostFree(ws.host_wins);
     }
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (hipStream_t l : ctx->lane)
+        if (l) (void)hipStreamDestroy(l);
     if (ctx->batch_evt) (void)hipEventDestroy(ctx->batch_evt);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
