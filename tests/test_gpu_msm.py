@@ -324,3 +324,55 @@ def test_fixed_base_tables_commit_identity_2_18(ctx):
         assert (out == exp).all() and inf == einf
     buf.free()
     ctx.srs_free(sid)
+
+
+def _mixed_scalars(rng, m):
+    """a random blend of the scalar classes the reference can meet: uniform, zero, one, r - 1, tiny, one repeated value"""
+    sc = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(m, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)          # < 2^254 < r: every limb pattern is a valid Montgomery residue
+    if m == 0:
+        return sc
+    cls = rng.integers(0, 6, size=m)
+    const = {1: 0, 2: O.fr_to_mont_limbs(1), 3: O.fr_to_mont_limbs(O.R - 1), 5: O.fr_to_mont_limbs(int(rng.integers(2, 1 << 40)))}
+    for k, v in const.items():
+        sc[cls == k] = np.array(v if v else [0, 0, 0, 0], dtype=np.uint64)
+    tiny = np.nonzero(cls == 4)[0]
+    for i in tiny:
+        sc[i] = np.array(O.fr_to_mont_limbs(int(rng.integers(0, 1 << 16))), dtype=np.uint64)
+    return sc
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_against_the_bucket_method_oracle(ctx, seed):
+    """random (SRS length, m, shard split, tables on/off, scalar mix): every variant of the device path equals the
+    CPU bucket-method MSM (oracle_msm_pippenger, itself checked against the reference-faithful path)"""
+    from oracle import coracle as CO
+
+    rng = np.random.default_rng(1000 + seed)
+    length = int(rng.integers(1, 40000)) if seed % 2 else int(rng.integers(1 << 15, 1 << 16))
+    s_limbs = np.array(O.fr_to_mont_limbs(int(rng.integers(2, 1 << 62))), dtype=np.uint64)
+    sid = ctx.srs_generate(s_limbs, length)
+    xy, inf = ctx.srs_download(sid)
+    tab = ctx.srs_generate(s_limbs, length)
+    ctx.srs_precompute(tab, 16 + seed % 5)
+    # the same SRS as two shards of unequal size
+    cut = int(rng.integers(0, length + 1))
+    lo_id = ctx.srs_generate(s_limbs, cut, start=0) if cut else None
+    hi_id = ctx.srs_generate(s_limbs, length - cut, start=cut) if cut < length else None
+    if lo_id is not None:
+        ctx.srs_set_shard(lo_id, 0, length)
+    if hi_id is not None:
+        ctx.srs_set_shard(hi_id, cut, length)
+    from typlonk_amd.capi import g1_sum_host
+    for m in sorted({0, 1, length, int(rng.integers(0, length + 1)), max(0, cut - 1), min(length, cut + 1)}):
+        sc = _mixed_scalars(rng, m)
+        exp, einf, _, _ = CO.msm_pippenger(sc, xy, inf, c=11)
+        for handle in (sid, tab):
+            got, ginf = ctx.msm(handle, sc)
+            assert (got == exp).all() and ginf == einf, (length, m, handle == tab)
+        parts = [ctx.msm(h, sc) for h in (lo_id, hi_id) if h is not None]
+        fxy, finf = g1_sum_host(np.stack([p[0] for p in parts]), np.array([p[1] for p in parts], dtype=np.uint8))
+        assert (fxy == exp).all() and finf == einf, (length, m, cut)
+    for h in (sid, tab, lo_id, hi_id):
+        if h is not None:
+            ctx.srs_free(h)
