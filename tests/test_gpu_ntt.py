@@ -58,7 +58,7 @@ def test_l0_identity_2_16(ctx):
     assert not ev[1:].any()
 
 
-@pytest.mark.parametrize("log_n", [14, 16, 17, 20, 22])
+@pytest.mark.parametrize("log_n", [14, 16, 17, 20, 22, 24])
 def test_roundtrip_and_spot_check_large(ctx, log_n):
     n = 1 << log_n
     x = rand_limbs(log_n, n)
@@ -124,7 +124,7 @@ def test_golden_ntt_fixtures(ctx):
         assert fr_unpack(ctx.ntt(v, L, inverse=True, coset=g)) == [int(x, 16) for x in case["coset7_inverse"]]
 
 
-@pytest.mark.parametrize("log_n", [16, 20, 22])
+@pytest.mark.parametrize("log_n", [16, 20, 22, 24])
 def test_full_size_vs_c_oracle(ctx, log_n):
     """BASELINE config sizes: whole-vector equality with the C restatement of ark-poly's radix-2 FFT"""
     from oracle import coracle as CO
@@ -134,3 +134,5 @@ def test_full_size_vs_c_oracle(ctx, log_n):
     g = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
     if log_n <= 20:
         assert (ctx.ntt(x, log_n, inverse=True, coset=g) == CO.ntt(x, log_n, inverse=True, coset=g)).all()
+    if log_n == 24:   # the quotient domain of a 2^22-row circuit: forward on the coset g = 7
+        assert (ctx.ntt(x, log_n, coset=g) == CO.ntt(x, log_n, coset=g)).all()
