@@ -111,6 +111,8 @@ struct typlonk_ctx {
     std::vector<ProfStage> prof;
     std::vector<std::pair<const char*, float>> prof_result;
     int msm_c_override = 0;
+    bool ntt_full_tables = true;   // TYPLONK_NTT_FULL_TABLES=0: compose twiddles / coset powers from two-level tables
+    uint32_t ntt_full_max_log = 24;
     bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
     bool msm_tree_reduce = false;  // TYPLONK_MSM_REDUCE=running: running-sum + small-multiple reduction (first version)
 };
@@ -240,6 +242,32 @@ int get_pow_table(typlonk_ctx* ctx, const std::string& key, const Fr& base, cons
     return upload_table(ctx, key, h, out);
 }
 
+// Full one-multiplication table built on the device from a two-level pair (launch_ntt_full_table); kept per
+// context like every other table.  Sizes above TYPLONK_NTT_FULL_MAX_LOG (default 2^24 entries = 512 MB) are not
+// built: *out stays empty and the kernel composes the factor from the two-level tables instead.
+int get_full_table(typlonk_ctx* ctx, const std::string& key, const Table& lo, const Table& hi, uint32_t h, uint64_t S,
+                   uint64_t n, Table* out) {
+    *out = Table{};
+    if (!ctx->ntt_full_tables || n > (1ull << ctx->ntt_full_max_log)) return TYPLONK_OK;
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return TYPLONK_OK;
+    }
+    Table t;
+    t.n = n;
+    hipError_t e = hipMalloc((void**)&t.d, n * sizeof(Fr));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return TYPLONK_OK;  // no room: fall back to the two-level tables
+    }
+    launch_ntt_full_table(lo.d, hi.d, h, S, n, t.d, ctx->stream);
+    HIPCHK(hipGetLastError());
+    ctx->tables[key] = t;
+    *out = t;
+    return TYPLONK_OK;
+}
+
 std::string fr_hex(const Fr& f) {
     char buf[80];
     snprintf(buf, sizeof(buf), "%08x%08x%08x%08x%08x%08x%08x%08x", f.v[7], f.v[6], f.v[5], f.v[4], f.v[3], f.v[2],
@@ -293,7 +321,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     }
 
     // coset / scaling tables
-    Table pre_lo{}, pre_hi{}, post_lo{}, post_hi{}, scale{};
+    Table pre_lo{}, pre_hi{}, post_lo{}, post_hi{}, scale{}, pre_full{}, post_full{};
     uint32_t pre_h = 0, post_h = 0;
     Fr n_inv = Fr::one();
     if (inverse) n_inv = fe_inv(fr_from_u64(N));
@@ -301,14 +329,16 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         Fr g;
         memcpy(g.v, coset_shift, sizeof(g.v));
         if (!inverse) {
-            int rc = get_pow2l(ctx, "cs:f:" + std::to_string(log_n) + ":" + fr_hex(g), g, Fr::one(), log_n, &pre_lo,
-                               &pre_hi, &pre_h);
+            const std::string key = "cs:f:" + std::to_string(log_n) + ":" + fr_hex(g);
+            int rc = get_pow2l(ctx, key, g, Fr::one(), log_n, &pre_lo, &pre_hi, &pre_h);
             if (rc) return rc;
+            if ((rc = get_full_table(ctx, key + ":full", pre_lo, pre_hi, pre_h, 0, N, &pre_full))) return rc;
         } else {
             Fr gi = fe_inv(g);
-            int rc = get_pow2l(ctx, "cs:i:" + std::to_string(log_n) + ":" + fr_hex(g), gi, n_inv, log_n, &post_lo,
-                               &post_hi, &post_h);
+            const std::string key = "cs:i:" + std::to_string(log_n) + ":" + fr_hex(g);
+            int rc = get_pow2l(ctx, key, gi, n_inv, log_n, &post_lo, &post_hi, &post_h);
             if (rc) return rc;
+            if ((rc = get_full_table(ctx, key + ":full", post_lo, post_hi, post_h, 0, N, &post_full))) return rc;
         }
     } else if (inverse) {
         int rc = get_pow_table(ctx, "ninv:" + std::to_string(log_n), Fr::one(), n_inv, 1, &scale);
@@ -345,6 +375,11 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             if (rc) return rc;
             a.tw_lo = lo.d;
             a.tw_hi = hi.d;
+            Table full;
+            rc = get_full_table(ctx, "tw:" + dir + ":" + std::to_string(lrow) + ":full:" + std::to_string(k), lo, hi, a.tw_h,
+                                a.S, row_len, &full);
+            if (rc) return rc;
+            a.tw_full = full.d;
             logT = std::min<uint32_t>(10 - k, ilog2_u64(a.S));
         } else {
             const uint64_t N1 = 1ull << ks[0];
@@ -357,6 +392,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             a.post_lo = post_lo.d;
             a.post_hi = post_hi.d;
             a.post_h = post_h;
+            a.post_full = post_full.d;
             a.scale = scale.d;
         }
         a.logT = logT;
@@ -364,6 +400,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             a.pre_lo = pre_lo.d;
             a.pre_hi = pre_hi.d;
             a.pre_h = pre_h;
+            a.pre_full = pre_full.d;
         }
         if (P == 1) {
             a.in = d_data;
@@ -781,6 +818,8 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_SORT")) ctx->msm_legacy_sort = (strcmp(e, "atomic") == 0);
     if (const char* e = getenv("TYPLONK_MSM_REDUCE")) ctx->msm_tree_reduce = (strcmp(e, "running") == 0);
     if (const char* e = getenv("TYPLONK_MSM_INFLIGHT")) ctx->msm_inflight = atoi(e);
+    if (const char* e = getenv("TYPLONK_NTT_FULL_TABLES")) ctx->ntt_full_tables = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_NTT_FULL_MAX_LOG")) ctx->ntt_full_max_log = (uint32_t)atoi(e);
     *out = ctx;
     return TYPLONK_OK;
 }

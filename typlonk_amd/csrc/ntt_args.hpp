@@ -24,6 +24,11 @@ struct NttPassArgs {
     const Fr* post_hi;
     const Fr* scale;   // n^-1 applied to the output of the last pass (plain inverse NTT)
     uint32_t pre_h, post_h;
+    // Full (one multiplication) tables, built once per size in HBM and laid out exactly like the data they
+    // multiply, so their loads coalesce with the data's.  NULL = compose the factor from the two-level tables.
+    const Fr* tw_full;    // inter-pass twiddles of this pass: [k_p * S + column], row_len entries
+    const Fr* pre_full;   // pre_lo/hi product, N entries
+    const Fr* post_full;  // post_lo/hi product (scale folded in), N entries
 };
 
 }  // namespace ty

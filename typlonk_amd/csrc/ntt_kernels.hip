@@ -58,7 +58,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
             const uint32_t t = idx & (T - 1), i = idx >> logT;
             const uint64_t g = base + (uint64_t)i * a.S + t;
             Fr x = ntt_ld(a.in + g);
-            if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
+            if (a.pre_full) x = fe_mul(x, ntt_ld(a.pre_full + g));
+            else if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
             ntt_st(tile + idx, x);
         }
     } else {
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
             const uint32_t i = idx & (M - 1), t = idx >> k;
             const uint64_t g = ((k1base + t) * a.Q + q) * M + i;
             Fr x = ntt_ld(a.in + g);
-            if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
+            if (a.pre_full) x = fe_mul(x, ntt_ld(a.pre_full + g));
+            else if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
             ntt_st(tile + ((i << logT) + t), x);
         }
     }
@@ -98,8 +100,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
             const uint32_t t = idx & (T - 1), kk = idx >> logT;
             const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
             Fr x = ntt_ld(tile + ((src << logT) + t));
-            const uint64_t e = (c0 + t) * (uint64_t)kk;
-            x = fe_mul(x, ntt_pow2l(a.tw_lo, a.tw_hi, a.tw_h, e));
+            if (a.tw_full) {
+                x = fe_mul(x, ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t)));
+            } else {
+                const uint64_t e = (c0 + t) * (uint64_t)kk;
+                x = fe_mul(x, ntt_pow2l(a.tw_lo, a.tw_hi, a.tw_h, e));
+            }
             ntt_st(a.out + (base + (uint64_t)kk * a.S + t), x);
         }
     } else {
@@ -110,11 +116,24 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
             const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
             Fr x = ntt_ld(tile + ((src << logT) + t));
             const uint64_t o = obase + t + a.out_stride * kk;
-            if (a.post_lo) x = fe_mul(x, ntt_pow2l(a.post_lo, a.post_hi, a.post_h, o));
+            if (a.post_full) x = fe_mul(x, ntt_ld(a.post_full + o));
+            else if (a.post_lo) x = fe_mul(x, ntt_pow2l(a.post_lo, a.post_hi, a.post_h, o));
             if (a.scale) x = fe_mul(x, ntt_ld(a.scale));
             ntt_st(a.out + o, x);
         }
     }
+}
+
+// out[idx] = lo/hi power at exponent (idx % S) * (idx / S) (S != 0: inter-pass twiddles) or idx (S == 0)
+__global__ __launch_bounds__(256) void ntt_full_table_kernel(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n,
+                                                             Fr* out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const uint64_t e = S ? (idx % S) * (idx / S) : idx;
+    ntt_st(out + idx, ntt_pow2l(lo, hi, h, e));
+}
+void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n, Fr* out, hipStream_t s) {
+    hipLaunchKernelGGL(ntt_full_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, h, S, n, out);
 }
 
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
