@@ -185,18 +185,24 @@ int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint6
 int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4], typlonk_proof_tail* out);
 /* Batched openings -- the reference's own to-do (/root/reference/README.md:4, "opening batching"); the proof
  * shape differs from proof.rs:178-192, so this is a separate pair of calls and round3 above stays the default.
- *   round3_evals   as round3, but returns the six evaluations and [t_lo], [t_mid], [t_hi] only
- *   round4_batched v (squeezed by the caller from those evaluations) -> w[0] = witness of
- *                  a + v b + v^2 c + v^3 Z + v^4 r at zeta, which equals sum_i v^i W_i of round3's witnesses
- *                  (a, b, c, Z, r order); w[1] = witness of Z at zeta*w.  9 MSMs per proof instead of 13. */
+ *   round3_evals   quotient, linearisation polynomial and the six evaluations -- no commitment yet
+ *   round4_batched v (squeezed by the caller from those evaluations) -> one batch of five MSMs: [t_lo], [t_mid],
+ *                  [t_hi]; w[0] = witness of a + v b + v^2 c + v^3 Z + v^4 r at zeta, which equals sum_i v^i W_i of
+ *                  round3's witnesses (a, b, c, Z, r order); w[1] = witness of Z at zeta*w.
+ * 9 MSMs per proof instead of 13.  (As in the reference, t is committed after zeta -- and here v -- are known:
+ * plonk/src/proof.rs:133-136 vs :181; the quotient commitments are never hashed.) */
 typedef struct typlonk_proof_evals {
-    uint64_t t_xy[3][12];
-    uint8_t t_inf[3];
     uint64_t evals[6][4];   /* same order as typlonk_proof_tail.evals */
 } typlonk_proof_evals;
+typedef struct typlonk_proof_batched {
+    uint64_t t_xy[3][12];
+    uint8_t t_inf[3];
+    uint64_t w_xy[2][12];
+    uint8_t w_inf[2];
+} typlonk_proof_batched;
 int typlonk_prover_round3_evals(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4],
                                 typlonk_proof_evals* out);
-int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], uint64_t w_xy[2][12], uint8_t w_inf[2]);
+int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlonk_proof_batched* out);
 void typlonk_prover_free(typlonk_prover* p);
 
 /* ---- device-resident Fr vectors (so an iNTT result feeds an MSM without crossing PCIe) ---------- */

@@ -128,8 +128,9 @@ def test_batched_round_order_is_enforced(ctx):
     w = (C.c_void_p * 3)(*[b.handle.value for b in wires])
     ctx._chk(lib.typlonk_prover_round1(ctx.h, sid, cid, w, None, C.byref(pr), C.byref(cxy), C.byref(cinf)))
     v = _limbs(5)
-    wxy, winf = ((C.c_uint64 * 12) * 2)(), (C.c_uint8 * 2)()
-    rc = lib.typlonk_prover_round4_batched(pr, v.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(wxy), C.byref(winf))
+    from typlonk_amd.capi import ProofBatched
+    pb = ProofBatched()
+    rc = lib.typlonk_prover_round4_batched(pr, v.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(pb))
     assert rc == ERR_INVALID_ARG
     lib.typlonk_prover_free(pr)
     for b in wires:

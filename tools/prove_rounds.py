@@ -3,7 +3,7 @@ import os, sys, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch, typlonk_amd
-from typlonk_amd.capi import ProofTail, ProofEvals, _u64p, _u8p
+from typlonk_amd.capi import ProofTail, ProofEvals, ProofBatched, _u64p, _u8p
 from typlonk_amd.circuits import SquaringChain
 from bench import fr_mont_limbs
 
@@ -36,8 +36,8 @@ for batched in (False, True):
             pe = ProofEvals()
             ctx._chk(lib.typlonk_prover_round3_evals(pr, _u64p(ch[2]), _u64p(ch[3]), C.byref(pe)))
             t.append(time.perf_counter())
-            wxy, winf = ((C.c_uint64 * 12) * 2)(), (C.c_uint8 * 2)()
-            ctx._chk(lib.typlonk_prover_round4_batched(pr, _u64p(ch[4]), C.byref(wxy), C.byref(winf)))
+            pb = ProofBatched()
+            ctx._chk(lib.typlonk_prover_round4_batched(pr, _u64p(ch[4]), C.byref(pb)))
         else:
             tail = ProofTail()
             ctx._chk(lib.typlonk_prover_round3(pr, _u64p(ch[2]), _u64p(ch[3]), C.byref(tail)))

@@ -48,7 +48,13 @@ class ProofTail(C.Structure):
 
 class ProofEvals(C.Structure):
     """typlonk_proof_evals"""
-    _fields_ = [("t_xy", (C.c_uint64 * 12) * 3), ("t_inf", C.c_uint8 * 3), ("evals", (C.c_uint64 * 4) * 6)]
+    _fields_ = [("evals", (C.c_uint64 * 4) * 6)]
+
+
+class ProofBatched(C.Structure):
+    """typlonk_proof_batched"""
+    _fields_ = [("t_xy", (C.c_uint64 * 12) * 3), ("t_inf", C.c_uint8 * 3), ("w_xy", (C.c_uint64 * 12) * 2),
+                ("w_inf", C.c_uint8 * 2)]
 
 
 _lib = None
@@ -97,7 +103,7 @@ def load_library() -> C.CDLL:
     lib.typlonk_prover_round2.argtypes = [vp, u64p, u64p, C.POINTER((C.c_uint64 * 4) * 3), u64p, u8p]
     lib.typlonk_prover_round3.argtypes = [vp, u64p, u64p, C.POINTER(ProofTail)]
     lib.typlonk_prover_round3_evals.argtypes = [vp, u64p, u64p, C.POINTER(ProofEvals)]
-    lib.typlonk_prover_round4_batched.argtypes = [vp, u64p, C.POINTER((C.c_uint64 * 12) * 2), C.POINTER(C.c_uint8 * 2)]
+    lib.typlonk_prover_round4_batched.argtypes = [vp, u64p, C.POINTER(ProofBatched)]
     lib.typlonk_prover_free.argtypes = [vp]
     lib.typlonk_prover_free.restype = None
     lib.typlonk_circuit_load.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -394,14 +400,13 @@ class Context:
                 pe = ProofEvals()
                 self._chk(lib.typlonk_prover_round3_evals(pr, _u64p(alpha), _u64p(zeta), C.byref(pe)))
                 evals = [np.array(pe.evals[i], dtype=np.uint64) for i in range(6)]
-                t_commit = fold([(np.array(pe.t_xy[i], dtype=np.uint64), int(pe.t_inf[i])) for i in range(3)])
                 v = np.ascontiguousarray(challenge_v(evals), dtype=np.uint64).reshape(4)
-                wxy = ((C.c_uint64 * 12) * 2)()
-                winf = (C.c_uint8 * 2)()
-                self._chk(lib.typlonk_prover_round4_batched(pr, _u64p(v), C.byref(wxy), C.byref(winf)))
+                pb = ProofBatched()
+                self._chk(lib.typlonk_prover_round4_batched(pr, _u64p(v), C.byref(pb)))
+                tw = fold([(np.array(pb.t_xy[i], dtype=np.uint64), int(pb.t_inf[i])) for i in range(3)] +
+                          [(np.array(pb.w_xy[i], dtype=np.uint64), int(pb.w_inf[i])) for i in range(2)])
                 return {
-                    "commit": commits, "z_commit": (zxy, int(zinf[0])), "t_commit": t_commit,
-                    "witness": fold([(np.array(wxy[i], dtype=np.uint64), int(winf[i])) for i in range(2)]),
+                    "commit": commits, "z_commit": (zxy, int(zinf[0])), "t_commit": tw[:3], "witness": tw[3:],
                     "evals": evals, "batched": True,
                 }
             tail = ProofTail()

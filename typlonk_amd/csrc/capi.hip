@@ -1330,11 +1330,9 @@ struct typlonk_prover {
     Fr beta, gamma, k[3];
     bool has_pi = true;
     int round = 0;
-    // batched-opening flow (round3_evals / round4_batched): zeta and the witness of Z at zeta*w
+    // batched-opening flow (round3_evals / round4_batched)
     bool evals_only = false;
     Fr zeta;
-    uint64_t zw_xy[12];
-    uint8_t zw_inf = 0;
 };
 
 namespace {
@@ -1542,21 +1540,10 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
     }
     if (!rc) rc = prover_open(p, p->r, n, ze, batched ? nullptr : p->q[5], &ev[5]);          // proof.rs:175
     if (!rc && batched) {
-        // the quotient slices and the one witness that does not depend on v: Z at zeta*w
-        const Fr* polys[4] = {p->t, p->t + n, p->t + 2 * n, p->q[4]};
-        const size_t m[4] = {n, n, n > 3 ? n - 3 : 0, n - 1};
-        uint64_t xy[4][12];
-        uint8_t inf[4];
-        rc = prover_commit_batch(p, polys, m, 4, &xy[0][0], inf);
-        if (!rc) {
-            memcpy(evals_out->t_xy, xy, 3 * 96);
-            memcpy(evals_out->t_inf, inf, 3);
-            memcpy(p->zw_xy, xy[3], 96);
-            p->zw_inf = inf[3];
-            for (int i = 0; i < 6; ++i) memcpy(evals_out->evals[i], ev[i].v, 32);
-            p->zeta = ze;
-            p->evals_only = true;
-        }
+        // evaluations only: every commitment of this shape is issued by round4_batched in ONE five-MSM batch
+        for (int i = 0; i < 6; ++i) memcpy(evals_out->evals[i], ev[i].v, 32);
+        p->zeta = ze;
+        p->evals_only = true;
     }
     // ---- the nine remaining commitments in one batch: 6 opening witnesses + 3 quotient slices (:181) ----
     if (!rc && !batched) {
@@ -1590,8 +1577,8 @@ int typlonk_prover_round3_evals(typlonk_prover* p, const uint64_t alpha[4], cons
     return prover_round3_core(p, alpha, zeta, nullptr, out);
 }
 
-int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], uint64_t w_xy[2][12], uint8_t w_inf[2]) {
-    if (!p || !v || !w_xy || !w_inf) return TYPLONK_ERR_INVALID_ARG;
+int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlonk_proof_batched* out) {
+    if (!p || !v || !out) return TYPLONK_ERR_INVALID_ARG;
     typlonk_ctx* ctx = p->ctx;
     if (p->round != 3 || !p->evals_only) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round4_batched must follow round3_evals");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1620,14 +1607,21 @@ int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], uint64
     Fr y;
     if (!rc) rc = prover_open(p, p->q[5], n, p->zeta, p->q[0], &y);
     if (!rc) {
-        const Fr* one[1] = {p->q[0]};
-        const size_t m[1] = {n - 1};
-        rc = prover_commit_batch(p, one, m, 1, &w_xy[0][0], &w_inf[0]);
-    }
-    if (!rc) {
-        memcpy(w_xy[1], p->zw_xy, 96);
-        w_inf[1] = p->zw_inf;
-        p->round = 4;
+        // one batch: [t_lo], [t_mid], [t_hi] (proof.rs:181), the witness of Z at zeta*w, the batched witness at zeta
+        const Fr* ms[5] = {p->t, p->t + n, p->t + 2 * n, p->q[4], p->q[0]};
+        const size_t m[5] = {n, n, n > 3 ? n - 3 : 0, n - 1, n - 1};
+        uint64_t xy[5][12];
+        uint8_t inf[5];
+        rc = prover_commit_batch(p, ms, m, 5, &xy[0][0], inf);
+        if (!rc) {
+            memcpy(out->t_xy, xy, 3 * 96);
+            memcpy(out->t_inf, inf, 3);
+            memcpy(out->w_xy[1], xy[3], 96);
+            out->w_inf[1] = inf[3];
+            memcpy(out->w_xy[0], xy[4], 96);
+            out->w_inf[0] = inf[4];
+            p->round = 4;
+        }
     }
     ctx->profiling = prof;
     return rc;
