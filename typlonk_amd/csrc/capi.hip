@@ -1341,16 +1341,50 @@ int prover_commit_batch(typlonk_prover* p, const Fr* const* polys, const size_t*
     for (size_t i = 0; i < count; ++i) ptrs[i] = polys[i];
     return msm_batch(p->ctx, p->srs_id, ptrs.data(), m, count, xy, inf);
 }
-int prover_open(typlonk_prover* p, const Fr* poly, uint64_t m, const Fr& z, Fr* q, Fr* y) {
+// ops_tmp layout of the prover's openings: [0, 8*2048) per-workgroup carries, then 16 result slots
+constexpr size_t PROVER_EVAL_BLOCKS = 8 * 2048;
+int prover_ops_tmp(typlonk_prover* p, Fr** blocks, Fr** slots) {
     typlonk_ctx* ctx = p->ctx;
-    int rc = ensure(ctx, ctx->ops_tmp, (2048 + 8) * sizeof(Fr));
+    int rc = ensure(ctx, ctx->ops_tmp, (PROVER_EVAL_BLOCKS + 16) * sizeof(Fr));
     if (rc) return rc;
-    Fr* blocks = (Fr*)ctx->ops_tmp.p;
-    launch_open(poly, m, z, q, blocks, blocks + 2048, ctx->stream);
+    *blocks = (Fr*)ctx->ops_tmp.p;
+    *slots = *blocks + PROVER_EVAL_BLOCKS;
+    return TYPLONK_OK;
+}
+// open() without waiting: p(z) lands in result slot `slot`, the quotient (if q) in q; stream-ordered
+int prover_open_async(typlonk_prover* p, const Fr* poly, uint64_t m, const Fr& z, Fr* q, int slot) {
+    Fr *blocks, *slots;
+    int rc = prover_ops_tmp(p, &blocks, &slots);
+    if (rc) return rc;
+    typlonk_ctx* ctx = p->ctx;
+    launch_open(poly, m, z, q, blocks, slots + slot, ctx->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(y, blocks + 2048, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    return TYPLONK_OK;
+}
+// evaluations of `count` <= 8 polynomials at z into slots first_slot..; stream-ordered
+int prover_eval_async(typlonk_prover* p, const Fr* const* polys, uint32_t count, uint64_t m, const Fr& z, int first_slot) {
+    Fr *blocks, *slots;
+    int rc = prover_ops_tmp(p, &blocks, &slots);
+    if (rc) return rc;
+    typlonk_ctx* ctx = p->ctx;
+    launch_eval_multi(polys, count, m, z, blocks, slots + first_slot, ctx->stream);
+    HIPCHK(hipGetLastError());
+    return TYPLONK_OK;
+}
+// one synchronisation for `count` result slots
+int prover_fetch(typlonk_prover* p, Fr* out, int count) {
+    typlonk_ctx* ctx = p->ctx;
+    Fr *blocks, *slots;
+    int rc = prover_ops_tmp(p, &blocks, &slots);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, slots, (size_t)count * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return TYPLONK_OK;
+}
+int prover_open(typlonk_prover* p, const Fr* poly, uint64_t m, const Fr& z, Fr* q, Fr* y) {
+    int rc = prover_open_async(p, poly, m, z, q, 0);
+    if (rc) return rc;
+    return prover_fetch(p, y, 1);
 }
 }  // namespace
 
@@ -1490,15 +1524,34 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
     Fr ev[6];
     const Fr w = fr_domain_root(log_n);
     const Fr zw = fe_mul(ze, w);
-    for (int i = 0; i < 3 && !rc; ++i) rc = prover_open(p, p->co[i], n, ze, batched ? nullptr : p->q[i], &ev[i]);
-    if (!rc) rc = prover_open(p, p->z, n, ze, batched ? nullptr : p->q[3], &ev[3]);
-    if (!rc) rc = prover_open(p, p->z, n, zw, p->q[4], &ev[4]);
-    // ---- linearisation polynomial (proof.rs:376-439) ----
-    Fr s0, s1, pi_z;
-    if (!rc) rc = prover_open(p, ce.coef + 5 * n, n, ze, nullptr, &s0);   // sigma_0(zeta)
-    if (!rc) rc = prover_open(p, ce.coef + 6 * n, n, ze, nullptr, &s1);   // sigma_1(zeta)
-    pi_z = Fr::zero();
-    if (!rc && p->has_pi) rc = prover_open(p, p->pi, n, ze, nullptr, &pi_z);  // public_eval, proof.rs:138
+    Fr s0, s1, pi_z = Fr::zero();
+    {
+        // ONE synchronisation for everything evaluated here.  Result slots: 0..3 = a, b, c, Z at zeta (with their
+        // quotients unless batched), 4, 5 = sigma_0, sigma_1 and 6 = the public-input polynomial at zeta (for the
+        // linearisation, proof.rs:376-439, :138), 8 = Z at zeta*w (always with its quotient)
+        Fr host[9];
+        const Fr* at_zeta[8];
+        uint32_t cnt = 0;
+        if (batched) {
+            for (int i = 0; i < 3; ++i) at_zeta[cnt++] = p->co[i];
+            at_zeta[cnt++] = p->z;
+        } else {
+            for (int i = 0; i < 3 && !rc; ++i) rc = prover_open_async(p, p->co[i], n, ze, p->q[i], i);
+            if (!rc) rc = prover_open_async(p, p->z, n, ze, p->q[3], 3);
+        }
+        const int first = batched ? 0 : 4;
+        at_zeta[cnt++] = ce.coef + 5 * n;             // sigma_0
+        at_zeta[cnt++] = ce.coef + 6 * n;             // sigma_1
+        if (p->has_pi) at_zeta[cnt++] = p->pi;
+        if (!rc) rc = prover_eval_async(p, at_zeta, cnt, n, ze, first);
+        if (!rc) rc = prover_open_async(p, p->z, n, zw, p->q[4], 8);
+        if (!rc) rc = prover_fetch(p, host, 9);
+        for (int i = 0; i < 4; ++i) ev[i] = host[i];
+        ev[4] = host[8];
+        s0 = host[4];
+        s1 = host[5];
+        if (p->has_pi) pi_z = host[6];
+    }
     if (!rc) {
         const Fr one = Fr::one();
         Fr zn = ze;  // zeta^n

@@ -62,6 +62,8 @@ struct LincombArgs {
     uint64_t n;
     uint32_t terms;
 };
+// p_k(z) for up to 8 polynomials of m <= 2^22 coefficients each; blocks: count * ceil(m/2048) Fr; y: count Fr
+void launch_eval_multi(const Fr* const* polys, uint32_t count, uint64_t m, const Fr& z, Fr* blocks, Fr* y, hipStream_t s);
 void launch_lincomb(const LincombArgs& a, hipStream_t s);
 
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s);

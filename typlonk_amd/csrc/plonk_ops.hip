@@ -217,6 +217,41 @@ __global__ __launch_bounds__(256) void open_finish_kernel(OpenArgs a) {
     }
 }
 
+// ---- evaluation of up to 8 polynomials of the same length at the same point: two launches in all -----------
+struct EvalMultiArgs {
+    const Fr* c[8];
+    uint64_t m;
+    Fr* blocks;     // count * nblk per-workgroup values
+    uint32_t nblk;
+    Fr* y;          // count device scalars
+    Fr zpow[32];
+};
+__global__ __launch_bounds__(256) void eval_multi_block_kernel(EvalMultiArgs a) {
+    __shared__ Fr lds[256];
+    Fr loc[8], ci;
+    const Fr g0 = horner_block(a.c[blockIdx.y], a.m, (uint64_t)blockIdx.x * 2048, Fr::zero(), a.zpow, 0, lds, loc, &ci);
+    if (threadIdx.x == 0) p_st(a.blocks + (uint64_t)blockIdx.y * a.nblk + blockIdx.x, g0);
+}
+// one workgroup per polynomial: p(z) = sum_b A_b (z^2048)^b
+__global__ __launch_bounds__(256) void eval_multi_top_kernel(EvalMultiArgs a) {
+    __shared__ Fr lds[256];
+    Fr loc[8], ci;
+    const Fr y = horner_block(a.blocks + (uint64_t)blockIdx.x * a.nblk, a.nblk, 0, Fr::zero(), a.zpow, 11, lds, loc, &ci);
+    if (threadIdx.x == 0) p_st(a.y + blockIdx.x, y);
+}
+void launch_eval_multi(const Fr* const* polys, uint32_t count, uint64_t m, const Fr& z, Fr* blocks, Fr* y, hipStream_t s) {
+    EvalMultiArgs a;
+    for (uint32_t k = 0; k < 8; ++k) a.c[k] = polys[k < count ? k : 0];
+    a.m = m;
+    a.blocks = blocks;
+    a.nblk = (uint32_t)((m + 2047) / 2048);
+    a.y = y;
+    a.zpow[0] = z;
+    for (int k = 1; k < 32; ++k) a.zpow[k] = fe_sqr(a.zpow[k - 1]);
+    hipLaunchKernelGGL(eval_multi_block_kernel, dim3(a.nblk, count), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(eval_multi_top_kernel, dim3(count), dim3(256), 0, s, a);
+}
+
 // ---- out[i] = sum_k scalar_k * poly_k[i]  (+ constant on coefficient 0) ---------------------------------
 __global__ __launch_bounds__(256) void lincomb_kernel(LincombArgs a) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
