@@ -1657,8 +1657,7 @@ int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlon
     int rc = TYPLONK_OK;
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
-    Fr y;
-    if (!rc) rc = prover_open(p, p->q[5], n, p->zeta, p->q[0], &y);
+    if (!rc) rc = prover_open_async(p, p->q[5], n, p->zeta, p->q[0], 0);  // F(zeta) itself is not needed: stream-ordered
     if (!rc) {
         // one batch: [t_lo], [t_mid], [t_hi] (proof.rs:181), the witness of Z at zeta*w, the batched witness at zeta
         const Fr* ms[5] = {p->t, p->t + n, p->t + 2 * n, p->q[4], p->q[0]};
