@@ -376,3 +376,29 @@ def test_random_shapes_against_the_bucket_method_oracle(ctx, seed):
     for h in (sid, tab, lo_id, hi_id):
         if h is not None:
             ctx.srs_free(h)
+
+
+def test_shard_argument_errors(ctx):
+    """typlonk_srs_set_shard: the slice must fit into total_len; the MSM length is checked against the TOTAL length
+    (the reference's assert, kzg/src/lib.rs:43), not the local one"""
+    from typlonk_amd.capi import TyplonkError, ERR_INVALID_ARG, ERR_LENGTH, ERR_RANGE
+
+    s_limbs = np.array(O.fr_to_mont_limbs(5), dtype=np.uint64)
+    sid = ctx.srs_generate(s_limbs, 10, start=20)
+    with pytest.raises(TyplonkError) as e:
+        ctx.srs_set_shard(sid, 25, 30)          # 25 + 10 > 30
+    assert e.value.code == ERR_RANGE
+    with pytest.raises(TyplonkError) as e:
+        ctx.srs_set_shard(9999, 0, 10)
+    assert e.value.code == ERR_INVALID_ARG
+    ctx.srs_set_shard(sid, 20, 40)
+    sc = np.tile(np.array(O.fr_to_mont_limbs(3), dtype=np.uint64), (41, 1))
+    with pytest.raises(TyplonkError) as e:
+        ctx.msm(sid, sc)                         # 41 > total_len
+    assert e.value.code == ERR_LENGTH
+    out, inf = ctx.msm(sid, sc[:15])             # m below the shard's first index: the empty sum
+    assert inf == 1
+    out, inf = ctx.msm(sid, sc[:40])             # 3 * sum_{i=20}^{29} 5^i G
+    exp = O.g1_mul(O.G1, 3 * sum(pow(5, i, O.R) for i in range(20, 30)) % O.R)
+    assert g1_unpack_one(out, inf) == exp
+    ctx.srs_free(sid)
