@@ -16,6 +16,69 @@ __device__ __forceinline__ G1Xyzz shfl_xor_point(const G1Xyzz& p, int mask) {
     return r;
 }
 
+__device__ __forceinline__ Fq30 shfl_xor_fq(const Fq30& a, int mask) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.v[i] = __shfl_xor(a.v[i], mask);
+    return r;
+}
+__device__ __forceinline__ Fq30 fq_sel(bool c, const Fq30& a, const Fq30& b) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+
+// v <- v + (value of lane ^ mask), on both lanes of every pair: the butterfly step of the reductions.
+// The two lanes of a pair split the 12M + 2S of add-2008-s between them (7 multiplication times instead of 14):
+// with a = the lower lane's point and b = the upper lane's,
+//   step 1  every lane: own.x * other.zz (U1 on the lower lane, U2 on the upper), own.y * other.zzz (S1 / S2);
+//           lower: a.zz * b.zz, upper: a.zzz * b.zzz                                  -> exchange
+//   step 2  lower: PP = P^2, upper: R^2  (P = U2 - U1, R = S2 - S1)                   -> exchange
+//   step 3  lower: PPP = P * PP, upper: Q = U1 * PP                                   -> exchange
+//   step 4  lower: R * (Q - X3) and ZZ12 * PP, upper: S1 * PPP and ZZZ12 * PPP        -> exchange
+// Bounds are those of g1_add (g1.hpp).  An identity operand selects the other point at the end.  Equal or opposite
+// points are rare: if ANY pair of the wavefront meets them, the whole wavefront takes the one-lane g1_add instead.
+__device__ __forceinline__ G1Xyzz butterfly_add(const G1Xyzz& v, int mask) {
+    const G1Xyzz o = shfl_xor_point(v, mask);
+    const bool lower = (threadIdx.x & (uint32_t)mask) == 0;
+    // step 1
+    const Fq30 u_own = fq30_mul(v.x, o.zz);                              // < 1.01
+    const Fq30 s_own = fq30_mul(v.y, o.zzz);                             // < 1.01
+    const Fq30 zz_own = fq30_mul(fq_sel(lower, v.zz, v.zzz), fq_sel(lower, o.zz, o.zzz));   // ZZ12 | ZZZ12  < 1.01
+    const Fq30 u_oth = shfl_xor_fq(u_own, mask), s_oth = shfl_xor_fq(s_own, mask), zz_oth = shfl_xor_fq(zz_own, mask);
+    const Fq30 u1 = fq_sel(lower, u_own, u_oth), u2 = fq_sel(lower, u_oth, u_own);
+    const Fq30 s1 = fq_sel(lower, s_own, s_oth), s2 = fq_sel(lower, s_oth, s_own);
+    const Fq30 zz12 = fq_sel(lower, zz_own, zz_oth), zzz12 = fq_sel(lower, zz_oth, zz_own);
+    const Fq30 pd = fq30_sub_lazy<2>(u2, u1);                            // < 3.1
+    const Fq30 rd = fq30_sub_lazy<2>(s2, s1);                            // < 3.1
+    // step 2
+    const Fq30 sq_own = fq30_sqr(fq_sel(lower, pd, rd));                 // PP | RR  < 1.02
+    const Fq30 sq_oth = shfl_xor_fq(sq_own, mask);
+    const Fq30 pp = fq_sel(lower, sq_own, sq_oth), rr = fq_sel(lower, sq_oth, sq_own);
+    // an identity operand just selects the other point below (the formulas then run on zeros, harmlessly);
+    // equal or opposite points need the doubling / identity branches of g1_add
+    const bool v_inf = v.is_inf(), o_inf = o.is_inf();
+    if (__any(!v_inf && !o_inf && fq30_is_zero_mod(pp))) return g1_add(v, o);
+    // step 3
+    const Fq30 m3_own = fq30_mul(fq_sel(lower, pd, u1), pp);             // PPP | Q  < 1.01
+    const Fq30 m3_oth = shfl_xor_fq(m3_own, mask);
+    const Fq30 ppp = fq_sel(lower, m3_own, m3_oth), q = fq_sel(lower, m3_oth, m3_own);
+    G1Xyzz out;
+    out.x = fq30_sub2_lazy<4>(rr, ppp, fq30_mulk_lazy<2>(q));           // < 5.1
+    const Fq30 t = fq30_sub_lazy<6>(q, out.x);                           // < 7.1
+    // step 4
+    const Fq30 y_own = fq30_mul(fq_sel(lower, rd, s1), fq_sel(lower, t, ppp));       // R*T | S1*PPP
+    const Fq30 z_own = fq30_mul(fq_sel(lower, zz12, zzz12), fq_sel(lower, pp, ppp));  // ZZ3 | ZZZ3  < 1.01
+    const Fq30 y_oth = shfl_xor_fq(y_own, mask), z_oth = shfl_xor_fq(z_own, mask);
+    out.y = fq30_sub_lazy<2>(fq_sel(lower, y_own, y_oth), fq_sel(lower, y_oth, y_own));   // R*T - S1*PPP  < 3.1
+    out.zz = fq_sel(lower, z_own, z_oth);
+    out.zzz = fq_sel(lower, z_oth, z_own);
+    if (v_inf) return o;
+    if (o_inf) return v;
+    return out;
+}
+
 // Thread t owns buckets [t*L, (t+1)*L) of the flat (window-major) bucket array, L = min(8, B).
 // node value = sum_l w(s*L + l) * bucket[l]   with s = t mod (B/L) and bucket weight
 // w(k) = (k >> v) + 1, v = 0 except in the top window (v = top_v, see msm_digits_kernel);
@@ -120,10 +183,7 @@ __global__ __launch_bounds__(64) void msm_fold_seq_kernel(FoldSeg a, FoldSeg b, 
         v = ld_xyzz(g.in, base);
         for (uint32_t i = 1; i < (1u << g.lseq); ++i) v = g1_add(v, ld_xyzz(g.in, base + i));
     }
-    for (uint32_t mask = 1; mask < g.lanes; mask <<= 1) {
-        const G1Xyzz o = shfl_xor_point(v, (int)mask);
-        v = g1_add(v, o);
-    }
+    for (uint32_t mask = 1; mask < g.lanes; mask <<= 1) v = butterfly_add(v, (int)mask);
     if (t < g.threads && (threadIdx.x & (g.lanes - 1)) == 0) st_xyzz(g.out, t / g.lanes, v);
 }
 
@@ -153,10 +213,7 @@ __global__ __launch_bounds__(64) void msm_rc_bits_kernel(const uint32_t* __restr
         const uint64_t at = kind ? ((uint64_t)sh.nsets << sh.ch) + ((uint64_t)set << sh.cl) + idx : ((uint64_t)set << sh.ch) + idx;
         v = ld_xyzz(sums, at);
     }
-    for (uint32_t mask = 1; mask < 64; mask <<= 1) {
-        const G1Xyzz o = shfl_xor_point(v, (int)mask);
-        v = g1_add(v, o);
-    }
+    for (uint32_t mask = 1; mask < 64; mask <<= 1) v = butterfly_add(v, (int)mask);
     if (threadIdx.x == 0) st_xyzz(bitsum, (uint64_t)((set * 2 + kind) * RC_NB + bit) * 64 + chunk, v);
 }
 
@@ -169,10 +226,7 @@ __global__ __launch_bounds__(64) void msm_rc_final_kernel(const uint32_t* __rest
     const uint32_t count = kind ? cw : rw;
     G1Xyzz v = G1Xyzz::inf();
     if (threadIdx.x < count) v = ld_xyzz(bitsum, (uint64_t)blockIdx.x * 64 + threadIdx.x);
-    for (uint32_t mask = 1; mask < count; mask <<= 1) {
-        const G1Xyzz o = shfl_xor_point(v, (int)mask);
-        v = g1_add(v, o);
-    }
+    for (uint32_t mask = 1; mask < count; mask <<= 1) v = butterfly_add(v, (int)mask);
     if (threadIdx.x == 0) st_xyzz(out, blockIdx.x, v);
 }
 
@@ -191,10 +245,7 @@ __global__ __launch_bounds__(64) void msm_rc_combine_kernel(const uint32_t* __re
     const uint32_t emax = max(nbr ? nbr - 1 + shift : 0u, nbc ? nbc - 1 : 0u);
     for (uint32_t i = 0; i < emax; ++i)
         if (i < e) v = g1_dbl(v);
-    for (uint32_t mask = 1; mask < 2 * RC_NB; mask <<= 1) {
-        const G1Xyzz o = shfl_xor_point(v, (int)mask);
-        v = g1_add(v, o);
-    }
+    for (uint32_t mask = 1; mask < 2 * RC_NB; mask <<= 1) v = butterfly_add(v, (int)mask);
     if (threadIdx.x == 0) st_xyzz(set_sums, set, v);
 }
 
