@@ -264,7 +264,7 @@ void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* 
         FoldSeg g;
         g.in = in;
         g.out = out;
-        g.lseq = lcnt < 2 ? lcnt : 2;
+        g.lseq = lcnt < 1 ? lcnt : 1;
         g.lanes = 1u << (lcnt - g.lseq);
         g.threads = n_in >> g.lseq;
         return g;
