@@ -25,3 +25,16 @@ def test_reference_kzg_and_l0_tests_cpp(built):
     out = _run("test_kzg_host")
     for t in ("commit ok", "scalar_mul ok", "l0 ok", "interpolate_then_commit ok"):
         assert t in out
+
+
+def test_poly_glue_under_address_and_ub_sanitizers(built, tmp_path):
+    """the host-side C++ (typlonk_host.hpp + the shared field headers) compiled with ASan + UBSan on the CPU build
+    (GPU sanitizers are not available on this pool): no report, same answers"""
+    exe = str(tmp_path / "test_poly_host_san")
+    lib = os.path.join(ROOT, "typlonk_amd")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           os.path.join(ROOT, "tests", "cpp", "test_poly_host.cpp"), "-o", exe, "-L", lib, "-ltyplonk_hip", "-Wl,-rpath," + lib]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("all ok"), r.stdout[-1000:] + r.stderr[-2000:]
