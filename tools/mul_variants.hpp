@@ -69,4 +69,103 @@ __device__ __forceinline__ Fq30 fq30_mul_ilp(const Fq30& a, const Fq30& b) {
     return fq30_redc(T);
 }
 
+// V5: the reduction adds the product digit T[k] with a mad (T[k] * 1 + acc) instead of zero-extending it and a
+// 64-bit add (v_mov + v_lshl_add_u64)
+__device__ __forceinline__ Fq30 fq30_redc_v5(const uint32_t (&T)[26]) {
+    uint32_t m[13];
+    Fq30 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(T[k]) : "vcc");
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
+        m[k] = ((uint32_t)acc * FQ30_NINV) & FQ30_MASK;
+        acc += (uint64_t)m[k] * fq30_kp(1, 0);
+        acc >>= 30;
+    }
+#pragma unroll
+    for (int k = 13; k < 26; ++k) {
+        asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(T[k]) : "vcc");
+#pragma unroll
+        for (int i = k - 12; i < 13; ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
+        r.v[k - 13] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    return r;
+}
+__device__ __forceinline__ Fq30 fq30_mul_v5(const Fq30& a, const Fq30& b) {
+    uint32_t T[26];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+#pragma unroll
+        for (int i = (k > 12 ? k - 12 : 0); i <= (k < 12 ? k : 12); ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        T[k] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    T[25] = (uint32_t)acc;
+    return fq30_redc_v5(T);
+}
+
+// V6: V5's reduction after the independent-column product phase of V4
+__device__ __forceinline__ Fq30 fq30_mul_v6(const Fq30& a, const Fq30& b) {
+    uint64_t col[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = (k > 12 ? k - 12 : 0); i <= (k < 12 ? k : 12); ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        col[k] = acc;
+    }
+    uint32_t T[26];
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+        c += col[k];
+        T[k] = (uint32_t)c & FQ30_MASK;
+        c >>= 30;
+    }
+    T[25] = (uint32_t)c;
+    return fq30_redc_v5(T);
+}
+// V7: V5 with the column carry folded into the first mad of the next column's m*p chain by keeping the chain in
+// one asm-visible accumulator (no separate partial chain to merge)
+__device__ __forceinline__ Fq30 fq30_redc_v7(const uint32_t (&T)[26]) {
+    uint32_t m[13];
+    Fq30 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(T[k]) : "vcc");
+#pragma unroll
+        for (int i = 0; i < k; ++i) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[i]), "s"(fq30_kp(1, k - i)) : "vcc");
+        m[k] = ((uint32_t)acc * FQ30_NINV) & FQ30_MASK;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[k]), "s"(fq30_kp(1, 0)) : "vcc");
+        acc >>= 30;
+    }
+#pragma unroll
+    for (int k = 13; k < 26; ++k) {
+        asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(T[k]) : "vcc");
+#pragma unroll
+        for (int i = k - 12; i < 13; ++i) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(m[i]), "s"(fq30_kp(1, k - i)) : "vcc");
+        r.v[k - 13] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    return r;
+}
+__device__ __forceinline__ Fq30 fq30_mul_v7(const Fq30& a, const Fq30& b) {
+    uint32_t T[26];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+#pragma unroll
+        for (int i = (k > 12 ? k - 12 : 0); i <= (k < 12 ? k : 12); ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        T[k] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    T[25] = (uint32_t)acc;
+    return fq30_redc_v7(T);
+}
+
 }  // namespace ty

@@ -64,6 +64,18 @@ __global__ __launch_bounds__(256) void fq_variant_kernel(uint32_t* out, int iter
         a.v[11] &= 0x0fffffffu; b.v[11] &= 0x0fffffffu;
         for (int i = 0; i < iters; ++i) { a = fe_mul_ps(a, b); b = fe_mul_ps(b, a); }
         for (int i = 0; i < 12; ++i) s += a.v[i] ^ b.v[i];
+    } else if (V == 6 || V == 7) {
+        Fq30 a, b;
+        for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & FQ30_MASK; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & FQ30_MASK; }
+        for (int i = 0; i < iters; ++i) {
+            if (V == 6) { a = fq30_mul_v6(a, b); b = fq30_mul_v6(b, a); } else { a = fq30_mul_v7(a, b); b = fq30_mul_v7(b, a); }
+        }
+        for (int i = 0; i < 13; ++i) s += a.v[i] ^ b.v[i];
+    } else if (V == 5) {
+        Fq30 a, b;
+        for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & FQ30_MASK; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & FQ30_MASK; }
+        for (int i = 0; i < iters; ++i) { a = fq30_mul_v5(a, b); b = fq30_mul_v5(b, a); }
+        for (int i = 0; i < 13; ++i) s += a.v[i] ^ b.v[i];
     } else if (V == 4) {
         Fq30 a, b;
         for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & FQ30_MASK; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & FQ30_MASK; }
@@ -154,6 +166,12 @@ int main() {
             double t2 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<2>, dim3(nb), dim3(threads), 0, 0, out, it); });
             double t3 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<3>, dim3(nb), dim3(threads), 0, 0, out, it); });
             double t4 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<4>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            double t5 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<5>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            double t6 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<6>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            double t7 = time_ms([&] { hipLaunchKernelGGL(fq_variant_kernel<7>, dim3(nb), dim3(threads), 0, 0, out, it); });
+            printf("Fq mul @%d blocks/CU: 13x30 with mad-add of T[k] %.2f | + indep columns %.2f | all-asm chain %.2f G mul/s\n", occ,
+                   (double)nb * threads * it * 2 / t5 * 1e-6, (double)nb * threads * it * 2 / t6 * 1e-6,
+                   (double)nb * threads * it * 2 / t7 * 1e-6);
             printf("Fq mul @%d blocks/CU: CIOS %.2f | product-scan asm %.2f | 13x30 %.2f | 13x30 indep-columns %.2f  G mul/s\n", occ,
                    (double)nb * threads * it * 2 / t1 * 1e-6, (double)nb * threads * it * 2 / t2 * 1e-6,
                    (double)nb * threads * it * 2 / t3 * 1e-6, (double)nb * threads * it * 2 / t4 * 1e-6);

@@ -80,6 +80,15 @@ TY_HD Fq30 fq30_one() {
     return r;
 }
 
+// acc += x for a 32-bit x.  On the device this is one v_mad_u64_u32 (x * 1 + acc): the compiler would otherwise
+// zero-extend x into a register pair and issue a 64-bit add (v_mov + v_lshl_add_u64), measurably slower
+// (tools/ubench: 72.1 -> 74.6 G Fq-mul/s).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FQ30_PLAIN_ADD32)
+#define FQ30_ACC_ADD32(acc, x) asm("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(acc) : "v"(x) : "vcc")
+#else
+#define FQ30_ACC_ADD32(acc, x) ((acc) += (x))
+#endif
+
 // ---- multiplication -----------------------------------------------------------------------------
 // Montgomery reduction of a 26-digit product T (T[25] may exceed 30 bits): T * 2^-390 mod p,
 // result < p + T / 2^390, normalised.
@@ -89,7 +98,7 @@ TY_HD Fq30 fq30_redc(const uint32_t (&T)[26]) {
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
-        acc += T[k];
+        FQ30_ACC_ADD32(acc, T[k]);
 #pragma unroll
         for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
         m[k] = ((uint32_t)acc * FQ30_NINV) & FQ30_MASK;
@@ -98,7 +107,7 @@ TY_HD Fq30 fq30_redc(const uint32_t (&T)[26]) {
     }
 #pragma unroll
     for (int k = 13; k < 26; ++k) {
-        acc += T[k];
+        FQ30_ACC_ADD32(acc, T[k]);
 #pragma unroll
         for (int i = k - 12; i < 13; ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
         r.v[k - 13] = (uint32_t)acc & FQ30_MASK;
