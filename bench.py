@@ -323,23 +323,26 @@ def main() -> None:
 
     if world > 1:
         # ---- prove() with every MSM sharded over the ranks (NTT / quotient replicated): typlonk_amd.dist.ShardedProver
-        from typlonk_amd.circuits import SquaringChain
-        from typlonk_amd.dist import ShardedProver
+        try:
+            from typlonk_amd.circuits import SquaringChain
+            from typlonk_amd.dist import ShardedProver
 
-        chain = SquaringChain(ctx, log_n)
-        ch = [fr_mont_limbs(0x1234567 + k) for k in range(4)]
-        sp = ShardedProver(sh)
-        run_s = lambda: sp.prove(chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731
-                                 lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]), challenge_v=lambda e: ch[1])
-        run_s()
-        sync_all()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            proof = run_s()
-        sync_all()
-        result["prove_sharded_batched_ms"] = (time.perf_counter() - t1) / 3 * 1e3
-        result["prove_valid"] = bool((proof["evals"][5] == np.zeros(4, dtype=np.uint64)).all())
-        chain.free()
+            chain = SquaringChain(ctx, log_n)
+            ch = [fr_mont_limbs(0x1234567 + k) for k in range(4)]
+            sp = ShardedProver(sh)
+            run_s = lambda: sp.prove(chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731
+                                     lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]), challenge_v=lambda e: ch[1])
+            run_s()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                proof = run_s()
+            sync_all()
+            result["prove_sharded_batched_ms"] = (time.perf_counter() - t1) / 3 * 1e3
+            result["prove_valid"] = bool((proof["evals"][5] == np.zeros(4, dtype=np.uint64)).all())
+            chain.free()
+        except Exception as e:  # the contract line above must survive a failure of this extra measurement
+            result["prove_sharded_error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0 and world > 1 and not args.no_cpu_baseline:
         # sharded result vs the reference's own test identity commit(p) == [p(s)]G (oracle = checker)
