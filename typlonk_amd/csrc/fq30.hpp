@@ -118,7 +118,7 @@ TY_HD Fq30 fq30_redc(const uint32_t (&T)[26]) {
 
 // a*b*2^-390 mod p.  Needs normalised limbs and a*b < 2^780; output < (1 + A*B/630) p for
 // a < A p, b < B p.  338 + 26 mads, no carry instructions inside a column.
-TY_HD Fq30 fq30_mul(const Fq30& a, const Fq30& b) {
+TY_HD Fq30 fq30_mul_split(const Fq30& a, const Fq30& b) {
     uint32_t T[26];
     uint64_t acc = 0;
 #pragma unroll
@@ -134,7 +134,7 @@ TY_HD Fq30 fq30_mul(const Fq30& a, const Fq30& b) {
 
 // a*a*2^-390 mod p: cross terms once with a doubled operand (91 mads in the product phase).
 // Column bound: 6 * 2^61 + 2^60 < 2^64.
-TY_HD Fq30 fq30_sqr(const Fq30& a) {
+TY_HD Fq30 fq30_sqr_split(const Fq30& a) {
     uint32_t T[26];
     uint32_t d[13];
 #pragma unroll
@@ -152,6 +152,151 @@ TY_HD Fq30 fq30_sqr(const Fq30& a) {
     T[25] = (uint32_t)acc;
     return fq30_redc(T);
 }
+
+
+// ==== fused product + reduction ==========================================================================
+//
+// fq30_mul forms the 26-digit product first (25 column normalisations: shift, mask, carry add) and
+// then reduces it (26 more, plus 26 "T[k] * 1 + acc" mads to bring the digits back in).  Here column k
+// of the product and column k of the reduction share a 64-bit accumulator,
+//     acc_k = carry + sum_i a_i b_(k-i) + sum_i m_i p_(k-i),
+// so a multiplication needs 26 normalisations instead of 51 and no digit re-adds: 338 + 13 multiplier
+// instructions instead of 338 + 13 + 26.
+//
+// Overflow.  The reduction part of a column is at most (2^30 - 1) * (sum of the limbs of p it meets)
+// <= 5.76 * 2^60 and every product term is < 2^60, so columns 0..9 and 15..25 stay below 2^64 whatever
+// the (normalised) inputs are.  Columns 10..14 can reach 1.24 * 2^64: there the reduction terms and the
+// first ten product terms (which provably fit) are accumulated first and only the remaining 11 terms of a
+// multiplication (8 of a squaring) capture the carry-out of the mad into a third word
+// (v_mad_u64_u32 ..., vcc + v_addc_co_u32).  The schedule below was computed with exact bounds by
+// tools/fq30_fused_bounds.py; tests/cpp and the GPU tests compare every variant with fq30_mul on
+// random and extreme (all-ones digits) inputs.
+//
+// Same contract as fq30_mul / fq30_sqr: normalised limbs, a*b < 2^780, result < p + a*b / 2^390.
+
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// (hi : acc) += a * b   with the carry out of the 64-bit accumulator counted in hi
+#define FQ30_MAC_CC_VV(acc, hi, a, b) \
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(hi) : "v"(a), "v"(b) : "vcc")
+#define FQ30_MAC_CC_VS(acc, hi, a, b) \
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(hi) : "v"(a), "s"(b) : "vcc")
+#else
+#define FQ30_MAC_CC_VV(acc, hi, a, b)                          \
+    do {                                                        \
+        const uint64_t _t = (uint64_t)(a) * (uint64_t)(b);      \
+        (acc) += _t;                                            \
+        (hi) += ((acc) < _t) ? 1u : 0u;                         \
+    } while (0)
+#define FQ30_MAC_CC_VS(acc, hi, a, b) FQ30_MAC_CC_VV(acc, hi, a, b)
+#endif
+
+// capture schedule (tools/fq30_fused_bounds.py): in columns 11..14 the product terms from index `FIRST` on,
+// and the closing m_k * p_0 of columns 10..12
+TY_HD constexpr bool fq30_fused_wide_col(int k) { return k >= 10 && k <= 14; }
+TY_HD constexpr bool fq30_fused_cap_last(int k) { return k >= 10 && k <= 12; }
+
+template <bool SQR>
+TY_HD Fq30 fq30_mulsqr_fused(const Fq30& a, const Fq30& b) {
+    constexpr int FIRST = SQR ? 5 : 10;  // index (in program order) of the first captured product term of a wide column
+    uint32_t m[13];
+    uint32_t d[13];
+    if (SQR) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) d[i] = a.v[i] << 1;
+    }
+    Fq30 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 26; ++k) {
+        uint32_t hi = 0;
+        const bool wide = fq30_fused_wide_col(k);
+        // reduction terms of this column: m_i p_(k-i), i < k (first half) / i >= k - 12 (second half)
+#pragma unroll
+        for (int i = (k > 12 ? k - 12 : 0); i < (k < 13 ? k : 13); ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
+        // product terms
+        if (k < 25) {
+            int idx = 0;
+            const int lo = (k > 12 ? k - 12 : 0), hi_i = (k < 12 ? k : 12);
+            if (SQR) {
+                if ((k & 1) == 0) {
+                    acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+                    ++idx;
+                }
+#pragma unroll
+                for (int i = lo; 2 * i < k; ++i) {
+                    if (wide && k >= 11 && idx >= FIRST) {
+                        FQ30_MAC_CC_VV(acc, hi, d[i], a.v[k - i]);
+                    } else {
+                        acc += (uint64_t)d[i] * a.v[k - i];
+                    }
+                    ++idx;
+                }
+            } else {
+#pragma unroll
+                for (int i = lo; i <= hi_i; ++i) {
+                    if (wide && k >= 11 && idx >= FIRST) {
+                        FQ30_MAC_CC_VV(acc, hi, a.v[i], b.v[k - i]);
+                    } else {
+                        acc += (uint64_t)a.v[i] * b.v[k - i];
+                    }
+                    ++idx;
+                }
+            }
+        }
+        if (k < 13) {
+            m[k] = ((uint32_t)acc * FQ30_NINV) & FQ30_MASK;
+            if (fq30_fused_cap_last(k)) {
+                FQ30_MAC_CC_VS(acc, hi, m[k], fq30_kp(1, 0));
+            } else {
+                acc += (uint64_t)m[k] * fq30_kp(1, 0);
+            }
+        } else {
+            r.v[k - 13] = (uint32_t)acc & FQ30_MASK;
+        }
+        acc >>= 30;
+        if (wide) acc |= (uint64_t)hi << 34;
+    }
+    return r;
+}
+
+TY_HD Fq30 fq30_mul_fused(const Fq30& a, const Fq30& b) { return fq30_mulsqr_fused<false>(a, b); }
+TY_HD Fq30 fq30_sqr_fused(const Fq30& a) { return fq30_mulsqr_fused<true>(a, a); }
+
+// ---- un-reduced products: a*b + c*d with ONE reduction -------------------------------------------------
+// 26 normalised digits of a*b (T[25] may exceed 30 bits)
+TY_HD void fq30_mul_wide(const Fq30& a, const Fq30& b, uint32_t (&T)[26]) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) {
+#pragma unroll
+        for (int i = (k > 12 ? k - 12 : 0); i <= (k < 12 ? k : 12); ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+        T[k] = (uint32_t)acc & FQ30_MASK;
+        acc >>= 30;
+    }
+    T[25] = (uint32_t)acc;
+}
+// (a*b + c*d) * 2^-390 mod p; needs a*b + c*d < 2^780; result < p + (a*b + c*d) / 2^390.
+// The digit sums are < 2^31 (T[25]: < 2^32 by the value bound), which fq30_redc takes as they are.
+TY_HD Fq30 fq30_mul2_add(const Fq30& a, const Fq30& b, const Fq30& c, const Fq30& d) {
+    uint32_t T[26], U[26];
+    fq30_mul_wide(a, b, T);
+    fq30_mul_wide(c, d, U);
+#pragma unroll
+    for (int k = 0; k < 26; ++k) T[k] += U[k];
+    return fq30_redc(T);
+}
+
+// ---- the multiplication the library uses ---------------------------------------------------------------
+// -DFQ30_SPLIT_MUL selects the two-phase form (product digits, then reduction) for A/B measurements
+// (tools/ubench2.hip); results are identical digit for digit.
+#if defined(FQ30_SPLIT_MUL)
+TY_HD Fq30 fq30_mul(const Fq30& a, const Fq30& b) { return fq30_mul_split(a, b); }
+TY_HD Fq30 fq30_sqr(const Fq30& a) { return fq30_sqr_split(a); }
+#else
+TY_HD Fq30 fq30_mul(const Fq30& a, const Fq30& b) { return fq30_mul_fused(a, b); }
+TY_HD Fq30 fq30_sqr(const Fq30& a) { return fq30_sqr_fused(a); }
+#endif
 
 // ---- lazy additive operations (no modular reduction; callers track bounds) -----------------------
 // a + b, normalised.  Value a + b must be < 2^390.

@@ -53,6 +53,17 @@ struct G1Xyzz {
     }
 };
 
+// r*t - y*w with ONE Montgomery reduction (fq30_mul2_add): r*t + (4p - y)*w.  Needs y <= 4p.
+// Result < 1 + (R*T + 4*W)/630 in units of p for r < R, t < T, w < W.
+// -DG1_SPLIT_Y3 keeps the two separately reduced products (A/B measurements, tools/ubench2.hip).
+TY_HD Fq30 g1_y3(const Fq30& r, const Fq30& t, const Fq30& y, const Fq30& w) {
+#if defined(G1_SPLIT_Y3)
+    return fq30_sub_lazy<2>(fq30_mul(r, t), fq30_mul(y, w));
+#else
+    return fq30_mul2_add(r, t, fq30_neg_lazy<4>(y), w);
+#endif
+}
+
 // 2*(x, y) for an affine non-identity point, x, y < 1.1  (dbl-2008-s-1 with ZZ = ZZZ = 1)
 TY_HD G1Xyzz g1_dbl_affine(const Fq30& x, const Fq30& y) {
     G1Xyzz r;
@@ -64,7 +75,7 @@ TY_HD G1Xyzz g1_dbl_affine(const Fq30& x, const Fq30& y) {
     const Fq30 m = fq30_mulk_lazy<3>(fq30_sqr(x));                     // 3 * 1.01 < 3.1
     r.x = fq30_sub_lazy<3>(fq30_sqr(m), fq30_mulk_lazy<2>(s));         // m(3.1,3.1) + 3 < 4.1   (2s < 2.1 <= 3)
     const Fq30 t = fq30_sub_lazy<5>(s, r.x);                           // 1.01 + 5 < 6.1         (X3 < 4.1 <= 5)
-    r.y = fq30_sub_lazy<2>(fq30_mul(m, t), fq30_mul(w, y));            // m(3.1,6.1) + 2 < 3.1   (w*y < 1.01 <= 2)
+    r.y = g1_y3(m, t, y, w);                                           // < 3.1   (split: m(3.1,6.1) + 2; merged: 1 + (3.1*6.1 + 4*1.01)/630)
     r.zz = v;
     r.zzz = w;
     return r;
@@ -82,7 +93,7 @@ TY_HD G1Xyzz g1_dbl(const G1Xyzz& p) {
     const Fq30 m = fq30_mulk_lazy<3>(fq30_sqr(p.x));                   // 3 * m(5.1,5.1) < 3.2
     r.x = fq30_sub_lazy<3>(fq30_sqr(m), fq30_mulk_lazy<2>(s));         // m(3.2,3.2) + 3 < 4.1
     const Fq30 t = fq30_sub_lazy<5>(s, r.x);                           // < 6.1
-    r.y = fq30_sub_lazy<2>(fq30_mul(m, t), fq30_mul(w, p.y));          // m(3.2,6.1) + 2 < 3.1   (w*Y < 1.01)
+    r.y = g1_y3(m, t, p.y, w);                                         // < 3.1   (Y < 3.2 <= 4)
     r.zz = fq30_mul(v, p.zz);                                          // < 1.01
     r.zzz = fq30_mul(w, p.zzz);                                        // < 1.01
     return r;
@@ -115,7 +126,7 @@ TY_HD void g1_madd_xy(G1Xyzz& acc, const Fq30& qx, const Fq30& qy) {
     const Fq30 q = fq30_mul(acc.x, pp);                                // m(5.1,1.09) < 1.01
     const Fq30 x3 = fq30_sub2_lazy<4>(fq30_sqr(r), ppp, fq30_mulk_lazy<2>(q));  // m(5.1,5.1) + 4 < 5.1  (ppp + 2q < 3.1 <= 4)
     const Fq30 t = fq30_sub_lazy<6>(q, x3);                            // 1.01 + 6 < 7.1
-    acc.y = fq30_sub_lazy<2>(fq30_mul(r, t), fq30_mul(acc.y, ppp));    // m(5.1,7.1) + 2 < 3.1   (Y1*ppp < 1.01)
+    acc.y = g1_y3(r, t, acc.y, ppp);                                   // < 3.1   (split: m(5.1,7.1) + 2; merged: 1 + (5.1*7.1 + 4*1.02)/630 < 1.07)
     acc.x = x3;
     acc.zz = fq30_mul(acc.zz, pp);                                     // < 1.01
     acc.zzz = fq30_mul(acc.zzz, ppp);                                  // < 1.01
@@ -148,7 +159,7 @@ TY_HD G1Xyzz g1_add(const G1Xyzz& a, const G1Xyzz& b) {
     G1Xyzz o;
     o.x = fq30_sub2_lazy<4>(fq30_sqr(r), ppp, fq30_mulk_lazy<2>(q));   // m(3.1,3.1) + 4 < 5.1
     const Fq30 t = fq30_sub_lazy<6>(q, o.x);                           // < 7.1
-    o.y = fq30_sub_lazy<2>(fq30_mul(r, t), fq30_mul(s1, ppp));         // m(3.1,7.1) + 2 < 3.1
+    o.y = g1_y3(r, t, s1, ppp);                                        // < 3.1   (s1 < 1.01 <= 4)
     o.zz = fq30_mul(fq30_mul(a.zz, b.zz), pp);                         // < 1.01
     o.zzz = fq30_mul(fq30_mul(a.zzz, b.zzz), ppp);                     // < 1.01
     return o;
