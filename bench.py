@@ -37,6 +37,9 @@ from typlonk_amd.dist import ShardedMsm, local_range  # noqa: E402
 
 FR_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# what actually bounds the accumulation: the vector-ALU rate of the XYZZ mixed addition, measured by the
+# self-checking micro-benchmark tools/ubench2 (profiles/r02_ubench2_fused_y3.txt: 2 waves/SIMD, 128-thread blocks)
+MIXED_ADD_CEILING = 6.97e9
 
 
 def fr_mont_limbs(x: int) -> np.ndarray:
@@ -50,6 +53,9 @@ def synthetic_scalars(n: int, seed: int, device) -> torch.Tensor:
     g.manual_seed(seed)
     t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
     t[:, 3] &= 0x3FFFFFFFFFFFFFFF
+    # the tensor is handed to the library as a raw device pointer (typlonk_*_devptr): finish torch's kernels first --
+    # the library reads in the order of ITS stream (typlonk.h, "STREAM ORDERING")
+    torch.cuda.synchronize(device)
     return t
 
 
@@ -79,6 +85,8 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=1 << 16,
                     help="terms of the workload timed on the CPU oracle (2^16 ~ 16 s on one host core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded-prove", action="store_true",
+                    help="N > 1: skip the extra measurement of prove() with every MSM sharded over the ranks")
     ap.add_argument("--tables", type=int, default=20,
                     help="window bits of the fixed-base tables built once per SRS shard (0 = none); used when the "
                          "shard has >= 2^19 points")
@@ -97,10 +105,14 @@ def main() -> None:
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1 or os.environ.get("TYPLONK_FORCE_COLLECTIVE") == "1":
+        import datetime
+
+        # a rank that dies must not leave its peers waiting for ever in a collective
+        tmo = datetime.timedelta(seconds=int(os.environ.get("TYPLONK_BENCH_PG_TIMEOUT", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     log_n = args.log_n
     n = 1 << log_n
@@ -173,7 +185,12 @@ def main() -> None:
                               "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, bytes per launch)",
                               "algorithmic_bytes": alg_bytes,
                               "kernel_ms": t_acc * 1e3, "mixed_adds_per_s": W * m_local / t_acc,
-                              "note": "integer-ALU-bound kernel; see DESIGN.md for the ALU roofline"}
+                              "limited_by": "valu",
+                              "valu": {"achieved": W * m_local / t_acc, "peak": MIXED_ADD_CEILING, "unit": "mixed adds/s",
+                                       "frac": W * m_local / t_acc / MIXED_ADD_CEILING,
+                                       "peak_source": "tools/ubench2 (profiles/r02_ubench2_fused_y3.txt)"},
+                              "note": "the HBM fraction is what the contract asks for; the kernel is integer-VALU-bound "
+                                      "(92 % of the issue slots, profiles/r01_pmc_sq_valu_msm.json) -- see DESIGN.md"}
 
     if rank == 0:
         # ---- NTT 2^log_n, resident data -----------------------------------------------------------
@@ -321,13 +338,25 @@ def main() -> None:
                 result["value"] = None
                 result["error"] = "GPU result differs from the oracle: number withheld"
 
-    if world > 1:
-        # ---- prove() with every MSM sharded over the ranks (NTT / quotient replicated): typlonk_amd.dist.ShardedProver
-        try:
-            from typlonk_amd.circuits import SquaringChain
-            from typlonk_amd.dist import ShardedProver
+    if world > 1 and not args.no_sharded_prove:
+        # ---- prove() with every MSM sharded over the ranks (NTT / quotient replicated): typlonk_amd.dist.ShardedProver.
+        # The block contains collectives, so the ranks AGREE on success before entering it and after it: a failure on
+        # one rank (OOM, HIP error) must not leave its peers blocked in an all-gather.  A rank that fails inside the
+        # timed proofs raises (its peers' collectives then end with the process-group timeout); nothing is swallowed.
+        def agree(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
 
+        from typlonk_amd.circuits import SquaringChain
+        from typlonk_amd.dist import ShardedProver
+
+        chain, setup_err = None, None
+        try:
             chain = SquaringChain(ctx, log_n)
+        except Exception as e:  # setup only: no collective has been entered yet
+            setup_err = f"{type(e).__name__}: {e}"
+        if agree(setup_err is None):
             ch = [fr_mont_limbs(0x1234567 + k) for k in range(4)]
             sp = ShardedProver(sh)
             run_s = lambda: sp.prove(chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731
@@ -340,9 +369,10 @@ def main() -> None:
             sync_all()
             result["prove_sharded_batched_ms"] = (time.perf_counter() - t1) / 3 * 1e3
             result["prove_valid"] = bool((proof["evals"][5] == np.zeros(4, dtype=np.uint64)).all())
+        else:
+            result["prove_sharded_error"] = setup_err or "setup failed on another rank"
+        if chain is not None:
             chain.free()
-        except Exception as e:  # the contract line above must survive a failure of this extra measurement
-            result["prove_sharded_error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0 and world > 1 and not args.no_cpu_baseline:
         # sharded result vs the reference's own test identity commit(p) == [p(s)]G (oracle = checker)

@@ -40,6 +40,9 @@ extern "C" {
 #define TYPLONK_ERR_HIP (-5)           /* a HIP runtime call failed; see typlonk_last_error               */
 #define TYPLONK_ERR_OOM (-6)           /* device allocation failed                                        */
 #define TYPLONK_ERR_RANGE (-7)         /* offset/length outside a device buffer                            */
+#define TYPLONK_ERR_UNSATISFIED (-8)   /* the witness does not satisfy the circuit: r(zeta) != 0.  The reference
+                                          panics (vanishes(), plonk/src/proof.rs:321, 361, 504-507) or produces a
+                                          proof its own verifier rejects (:234-235)                          */
 
 typedef struct typlonk_ctx typlonk_ctx; /* one HIP device + stream + workspaces + cached NTT plans */
 typedef struct typlonk_buf typlonk_buf; /* device-resident vector of Fr elements                   */
@@ -50,7 +53,15 @@ void typlonk_destroy(typlonk_ctx* ctx);
 const char* typlonk_strerror(int code);
 const char* typlonk_last_error(const typlonk_ctx* ctx); /* detail text of the last failure on ctx  */
 /* Run all subsequent work of `ctx` on an existing hipStream_t (e.g. the caller's torch stream);
- * NULL restores the context's own stream. */
+ * NULL restores the context's own stream.
+ *
+ * STREAM ORDERING of device-resident inputs.  Every entry point that reads caller-owned device memory
+ * (typlonk_msm_g1_devptr, typlonk_msm_g1_batch_devptr, typlonk_ntt_fr_devptr, and the typlonk_buf forms when the
+ * buffer was written through typlonk_buf_devptr) reads it in the order of the CONTEXT'S STREAM.  The context's own
+ * stream is an ordinary (blocking) HIP stream, so it is also ordered after everything previously submitted to the
+ * legacy default stream -- which is where PyTorch-ROCm runs unless told otherwise.  A producer on any OTHER stream
+ * (a non-blocking stream, a torch side stream) must either be synchronised before the call or be made the
+ * context's stream with typlonk_set_stream; otherwise the MSM / NTT may read half-written input. */
 int typlonk_set_stream(typlonk_ctx* ctx, void* hip_stream);
 int typlonk_sync(typlonk_ctx* ctx);
 
@@ -64,7 +75,9 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
 int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_t count, uint64_t* xy, uint8_t* inf);
 /* Optional fixed-base precomputation (the SRS is immutable per circuit, plonk/src/lib.rs:22): builds the
  * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM, c = window_bits in
- * 16..20; 20 is the balanced choice: its top window still has 15 bits).  Later MSMs of at least len/4
+ * 16..20; 20 is the balanced choice: its top window still has 15 bits; a (len, window_bits) pair whose
+ * table-mode sort shape is not supported -- len > 2^22 with 20 bits -- is refused with TYPLONK_ERR_LENGTH and
+ * the SRS stays usable without tables).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
  * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point. */
 int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bits);
@@ -182,6 +195,10 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
                           uint8_t commit_inf[3]);
 int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t cosets[3][4],
                           uint64_t z_xy[12], uint8_t* z_inf);
+/* round3 / round3_evals return TYPLONK_ERR_UNSATISFIED when r(zeta) != 0 (the identity the verifier checks,
+ * proof.rs:234-235): the witness does not satisfy the circuit and the quotient had a remainder the slices silently
+ * drop.  `out` is completely filled in that case too (what the reference's verifier would be handed), but the
+ * proof will not verify. */
 int typlonk_prover_round3(typlonk_prover* p, const uint64_t alpha[4], const uint64_t zeta[4], typlonk_proof_tail* out);
 /* Batched openings -- the reference's own to-do (/root/reference/README.md:4, "opening batching"); the proof
  * shape differs from proof.rs:178-192, so this is a separate pair of calls and round3 above stays the default.

@@ -42,12 +42,13 @@ def _gpu_prove(ctx, sid, cid, cols, n, pi_evals=None, batched=False):
     wires = [_up(ctx, c, n) for c in cols]
     pi = _up(ctx, pi_evals or [0] * n, n)
     alpha, beta, gamma = CH
-    proof = ctx.prove(sid, cid, wires, pi, [_limbs(k) for k in PO.COSETS],
-                      lambda commits: (_limbs(beta), _limbs(gamma)), lambda commits: (_limbs(alpha), _limbs(ZETA)),
-                      challenge_v=(lambda evals: _limbs(V_BATCH)) if batched else None)
-    for b in wires + [pi]:
-        b.free()
-    return proof
+    try:
+        return ctx.prove(sid, cid, wires, pi, [_limbs(k) for k in PO.COSETS],
+                         lambda commits: (_limbs(beta), _limbs(gamma)), lambda commits: (_limbs(alpha), _limbs(ZETA)),
+                         challenge_v=(lambda evals: _limbs(V_BATCH)) if batched else None)
+    finally:
+        for b in wires + [pi]:
+            b.free()
 
 
 @pytest.mark.parametrize("log_n", [3, 4, 6])
@@ -268,9 +269,16 @@ def test_readme_pythagorean_circuit(ctx):
     assert [pt(w) for w in got["witness"]] == [o[0] for o in ref["open"]] + [ref["z_open"][0], ref["zw_open"][0], ref["r_open"][0]]
     assert fr(got["evals"][5]) == 0
     # bad inputs (circuit2_test_bad_inputs): the copy constraint c_3 ~ c_2 fails, the verifier's r(zeta) != 0
+    # (the reference test is #[should_panic]; here the prover reports TYPLONK_ERR_UNSATISFIED, in both proof shapes,
+    #  and the context is usable afterwards)
+    from typlonk_amd.capi import ERR_UNSATISFIED, TyplonkError
     _, bad_cols, _, _ = PO.pythagorean_circuit([3, 4, 6])
-    bad = _gpu_prove(ctx, sid, cid, bad_cols, n)
-    assert fr(bad["evals"][5]) != 0
+    for batched in (False, True):
+        with pytest.raises(TyplonkError) as e:
+            _gpu_prove(ctx, sid, cid, bad_cols, n, batched=batched)
+        assert e.value.code == ERR_UNSATISFIED
+    again = _gpu_prove(ctx, sid, cid, cols, n)
+    assert [pt(c) for c in again["commit"]] == ref["commit"] and fr(again["evals"][5]) == 0
     ctx.circuit_free(cid)
     ctx.srs_free(sid)
 

@@ -1,0 +1,124 @@
+"""GPU tests of the library's behaviour around the hot path: stream ordering of raw device pointers, the bounded
+coset-table cache, set-up calls that must not break later MSMs.  Bit-exact comparisons with the CPU oracle."""
+import numpy as np
+import pytest
+
+from helpers import O, fr_pack, fr_unpack, g1_unpack_one
+
+pytestmark = pytest.mark.gpu
+
+
+def _limbs(x):
+    return np.array(O.fr_to_mont_limbs(x), dtype=np.uint64)
+
+
+def test_devptr_calls_are_ordered_after_the_default_stream(ctx):
+    """typlonk.h, "STREAM ORDERING": the context's own stream is ordered after the legacy default stream, where torch
+    runs.  A long chain of torch kernels rewrites the vector and the library is called WITHOUT a synchronisation in
+    between: it must see the final contents (NTT and MSM), exactly as after an explicit synchronize."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    log_n, n = 16, 1 << 16
+    sid = ctx.srs_generate(_limbs(0x5151), n)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    base = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=dev, generator=g)
+    base[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    filler = torch.ones((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        y = base.clone()
+        for k in range(20):
+            filler = filler @ filler * 0 + 1            # keeps the default stream busy for a while
+            y[:, 0] += 0x1234567 * (k + rep + 1)          # ... while the input is still being rewritten
+            y[:, 3] &= 0x0FFFFFFFFFFFFFFF
+        got_msm = ctx.msm_devptr(sid, y.data_ptr(), n)   # no synchronize: ordering comes from the stream semantics
+        z = y.clone()
+        ctx.ntt_devptr(z.data_ptr(), log_n)
+        ctx.sync()
+        torch.cuda.synchronize()
+        want = y.cpu().numpy().view(np.uint64)
+        ref_msm = ctx.msm(sid, want)                       # host path: upload of the finished vector
+        assert (got_msm[0] == ref_msm[0]).all() and got_msm[1] == ref_msm[1]
+        assert (z.cpu().numpy().view(np.uint64) == ctx.ntt(want, log_n)).all()
+    ctx.srs_free(sid)
+
+
+def test_set_stream_binds_a_torch_side_stream(ctx):
+    """a producer on a NON-default stream: the context is bound to it (typlonk_set_stream) and reads in its order"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    log_n, n = 14, 1 << 14
+    side = torch.cuda.Stream(device=dev)
+    v = O.random_frs(0xABCD, n)
+    host = torch.from_numpy(fr_pack(v).view(np.int64))
+    try:
+        ctx.set_stream(side.cuda_stream)
+        with torch.cuda.stream(side):
+            d = host.to(dev, non_blocking=False)
+            for _ in range(10):
+                d = d.clone()
+            ctx.ntt_devptr(d.data_ptr(), log_n)
+        ctx.sync()
+        side.synchronize()
+        assert fr_unpack(d.cpu().numpy().view(np.uint64)) == O.ntt(v, log_n)
+    finally:
+        ctx.set_stream(None)
+
+
+def test_coset_table_cache_is_bounded_and_stays_correct(ctx):
+    """coset tables are keyed by the caller's shift: more distinct shifts than the cache holds (8 groups) are served
+    correctly -- evicted groups are rebuilt -- forward and inverse, and the quotient's generator keeps working"""
+    log_n, n = 10, 1 << 10
+    v = O.random_frs(0xC0C0, n)
+    packed = fr_pack(v)
+    shifts = [7, 5, 11, 13, 17, 19, 23, 29, 31, 37, 41, 7, 5]
+    for s in shifts:
+        g = _limbs(s)
+        assert fr_unpack(ctx.ntt(packed, log_n, coset=g)) == O.ntt(v, log_n, coset=s)
+    for s in (43, 7):
+        g = _limbs(s)
+        assert fr_unpack(ctx.ntt(packed, log_n, inverse=True, coset=g)) == O.ntt(v, log_n, inverse=True, coset=s)
+
+
+def test_precompute_refuses_a_shape_it_cannot_serve_and_the_srs_stays_usable(ctx):
+    """len in (2^22, 2^23] with 20-bit windows has no table-mode sort shape; typlonk_srs_precompute must
+    refuse it (TYPLONK_ERR_LENGTH) instead of breaking every later MSM over that SRS"""
+    from typlonk_amd.capi import ERR_LENGTH, TyplonkError
+
+    n = (1 << 22) + 5
+    secret = 3
+    sid = ctx.srs_generate(_limbs(secret), n)
+    with pytest.raises(TyplonkError) as e:
+        ctx.srs_precompute(sid, 20)
+    assert e.value.code == ERR_LENGTH
+    # plain path still works, short and full length: commit(p) == [p(s)]G (kzg/src/lib.rs:102-105)
+    for m in (1000, n):
+        rng = np.random.default_rng(m)
+        sc = rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+        sc[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        out, oinf = ctx.msm(sid, sc)
+        from oracle import coracle as CO
+        ps = CO.poly_eval(sc, _limbs(secret))
+        exp_xy, exp_inf = CO.g1_mul_generator(ps)
+        assert (out == exp_xy).all() and oinf == exp_inf
+    ctx.srs_free(sid)
+
+
+def test_msm_results_identical_with_and_without_profiling(ctx):
+    n = 1 << 12
+    sid = ctx.srs_generate(_limbs(0x77), n)
+    rng = np.random.default_rng(5)
+    sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    a = ctx.msm(sid, sc)
+    ctx.set_profiling(True)
+    b = ctx.msm(sid, sc)
+    names = [nm for nm, _ in ctx.profile()]
+    ctx.set_profiling(False)
+    assert (a[0] == b[0]).all() and a[1] == b[1]
+    assert any(nm.startswith("msm_accum") for nm in names)
+    assert g1_unpack_one(a[0], a[1]) is not None
+    ctx.srs_free(sid)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtyplonk_hip.so")
 
 OK = 0
-ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
+ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RANGE, ERR_UNSATISFIED = -1, -2, -3, -4, -5, -6, -7, -8
 
 # every symbol include/typlonk.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -219,6 +219,10 @@ class Context:
             pass
 
     def set_stream(self, stream_handle: int | None):
+        """run the context's work on an existing hipStream_t (None / 0 = the context's own stream).  The *_devptr
+        calls read caller memory in the order of the context's stream (see typlonk_set_stream in typlonk.h): the
+        own stream is ordered after the legacy default stream, any other producer stream must be bound here
+        (torch: `ctx.set_stream(torch.cuda.current_stream().cuda_stream)`) or synchronised first"""
         self._chk(self.lib.typlonk_set_stream(self.h, stream_handle))
 
     def sync(self):
@@ -368,7 +372,9 @@ class Context:
         challenge_v(evals) -> v selects the batched-opening shape (round3_evals + round4_batched):
         "witness" then holds [W at zeta of a + v b + v^2 c + v^3 Z + v^4 r, W of Z at zeta*w].
         fold(points) -> points combines per-rank partial commitments when `sid` is an SRS shard
-        (typlonk_srs_set_shard): one all-gather + fixed-order sum per round (typlonk_amd.dist.ShardedProver)."""
+        (typlonk_srs_set_shard): one all-gather + fixed-order sum per round (typlonk_amd.dist.ShardedProver).
+        Raises TyplonkError(ERR_UNSATISFIED) when r(zeta) != 0, i.e. the witness does not satisfy the circuit (the
+        reference panics in vanishes() or hands its verifier a proof it rejects, plonk/src/proof.rs:321, 361, 234)."""
         fold = fold or (lambda pts: pts)
         if challenge12 is None or challenge34 is None:
             # the reference's own Fiat-Shamir (plonk/src/proof/challenges.rs), see typlonk_amd/transcript.py

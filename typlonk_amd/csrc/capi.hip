@@ -42,6 +42,7 @@ struct SrsEntry {
 struct Table {
     Fr* d = nullptr;
     size_t n = 0;
+    uint64_t last_use = 0;  // typlonk_ctx::table_tick at the last lookup (coset tables are evicted LRU)
 };
 
 // Per-circuit constants of the quotient: the 4n coset evaluations of q_l q_r q_o q_m q_c, sigma_0..2
@@ -106,6 +107,11 @@ struct typlonk_ctx {
     DevBuf ntt_scratch, ntt_io, quot_ext, ops_tmp, prover_mem;
     bool prover_busy = false;  // one proof in flight per context (the arena above is shared)
     std::map<std::string, Table> tables;
+    uint64_t table_tick = 0;
+    // tables keyed by a caller-chosen coset shift ("cs:" keys) are a cache, not a plan: at most this many distinct
+    // (direction, size, shift) groups / bytes stay resident, the least recently used group is dropped first
+    static constexpr size_t COSET_GROUPS_MAX = 8;
+    static constexpr size_t COSET_BYTES_MAX = (size_t)3 << 30;
     // profiling
     bool profiling = false;
     std::vector<ProfStage> prof;
@@ -148,6 +154,28 @@ void release(DevBuf& b) {
     b.p = nullptr;
     b.cap = 0;
 }
+
+// Frees the device allocations registered with it unless dismiss()ed: setup functions allocate several
+// buffers and may fail half-way (HIPCHK returns early).
+struct DevGuard {
+    std::vector<void*> ptrs;
+    void* add(void* p) {
+        ptrs.push_back(p);
+        return p;
+    }
+    void dismiss() { ptrs.clear(); }
+    ~DevGuard() {
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+};
+// Stage events are per call: composite calls switch them off for their inner calls and restore on every exit path.
+struct ProfilingOff {
+    typlonk_ctx* ctx;
+    bool saved;
+    explicit ProfilingOff(typlonk_ctx* c) : ctx(c), saved(c->profiling) { c->profiling = false; }
+    ~ProfilingOff() { ctx->profiling = saved; }
+};
 
 // ---- profiling ------------------------------------------------------------------------------
 struct StageTimer {
@@ -218,9 +246,13 @@ Fr fr_from_u64(uint64_t x) {
 int upload_table(typlonk_ctx* ctx, const std::string& key, const std::vector<Fr>& h, Table* out) {
     Table t;
     t.n = h.size();
+    t.last_use = ++ctx->table_tick;
     HIPCHK(hipMalloc((void**)&t.d, h.size() * sizeof(Fr)));
+    DevGuard g;
+    g.add(t.d);
     HIPCHK(hipMemcpyAsync(t.d, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // h goes out of scope
+    g.dismiss();
     ctx->tables[key] = t;
     *out = t;
     return TYPLONK_OK;
@@ -230,6 +262,7 @@ int upload_table(typlonk_ctx* ctx, const std::string& key, const std::vector<Fr>
 int get_pow_table(typlonk_ctx* ctx, const std::string& key, const Fr& base, const Fr& scale, size_t n, Table* out) {
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
+        it->second.last_use = ++ctx->table_tick;
         *out = it->second;
         return TYPLONK_OK;
     }
@@ -251,18 +284,25 @@ int get_full_table(typlonk_ctx* ctx, const std::string& key, const Table& lo, co
     if (!ctx->ntt_full_tables || n > (1ull << ctx->ntt_full_max_log)) return TYPLONK_OK;
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
+        it->second.last_use = ++ctx->table_tick;
         *out = it->second;
         return TYPLONK_OK;
     }
     Table t;
     t.n = n;
+    t.last_use = ++ctx->table_tick;
     hipError_t e = hipMalloc((void**)&t.d, n * sizeof(Fr));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return TYPLONK_OK;  // no room: fall back to the two-level tables
     }
     launch_ntt_full_table(lo.d, hi.d, h, S, n, t.d, ctx->stream);
-    HIPCHK(hipGetLastError());
+    {
+        DevGuard g;
+        g.add(t.d);
+        HIPCHK(hipGetLastError());
+        g.dismiss();
+    }
     ctx->tables[key] = t;
     *out = t;
     return TYPLONK_OK;
@@ -286,6 +326,47 @@ int get_pow2l(typlonk_ctx* ctx, const std::string& key, const Fr& base, const Fr
     Fr step = base;
     for (uint32_t i = 0; i < h; ++i) step = fe_sqr(step);
     return get_pow_table(ctx, key + ":hi", step, hi_scale, (size_t)1 << (log_len - h), hi);
+}
+
+// Coset tables are keyed by the caller's shift ("cs:<dir>:<log_n>:<shift hex>..."): a caller that varies the shift
+// would otherwise grow HBM without bound.  Before a new group is built, drop least-recently-used groups until the
+// cache is inside its limits (the quotient's generator 7 is looked up on every proof and therefore stays).
+int evict_coset_tables(typlonk_ctx* ctx, const std::string& incoming_group, size_t incoming_bytes) {
+    if (ctx->tables.count(incoming_group + ":lo")) return TYPLONK_OK;  // resident (the per-proof case)
+    for (;;) {
+        std::map<std::string, std::pair<uint64_t, size_t>> groups;  // group -> (last use, bytes)
+        size_t bytes = 0;
+        for (const auto& kv : ctx->tables) {
+            if (kv.first.compare(0, 3, "cs:") != 0) continue;
+            size_t cut = kv.first.find(':', kv.first.find(':', kv.first.find(':', 3) + 1) + 1);  // after the shift hex
+            const std::string grp = kv.first.substr(0, cut);
+            auto& g = groups[grp];
+            g.first = std::max(g.first, kv.second.last_use);
+            g.second += kv.second.n * sizeof(Fr);
+            bytes += kv.second.n * sizeof(Fr);
+        }
+        if (groups.count(incoming_group)) return TYPLONK_OK;  // already resident: nothing new is built
+        if (groups.size() < typlonk_ctx::COSET_GROUPS_MAX && bytes + incoming_bytes <= typlonk_ctx::COSET_BYTES_MAX)
+            return TYPLONK_OK;
+        if (groups.empty()) return TYPLONK_OK;
+        std::string victim;
+        uint64_t oldest = ~0ull;
+        for (const auto& g : groups)
+            if (g.second.first < oldest) {
+                oldest = g.second.first;
+                victim = g.first;
+            }
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // kernels still reading the victim's tables
+        for (auto it = ctx->tables.begin(); it != ctx->tables.end();) {
+            if (it->first.compare(0, victim.size(), victim) == 0 &&
+                (it->first.size() == victim.size() || it->first[victim.size()] == ':')) {
+                (void)hipFree(it->second.d);
+                it = ctx->tables.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
 }
 
 void split_log(uint32_t L, uint32_t ks[4], uint32_t* P) {
@@ -330,13 +411,17 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         memcpy(g.v, coset_shift, sizeof(g.v));
         if (!inverse) {
             const std::string key = "cs:f:" + std::to_string(log_n) + ":" + fr_hex(g);
-            int rc = get_pow2l(ctx, key, g, Fr::one(), log_n, &pre_lo, &pre_hi, &pre_h);
+            int rc = evict_coset_tables(ctx, key, (size_t)N * sizeof(Fr));
+            if (rc) return rc;
+            rc = get_pow2l(ctx, key, g, Fr::one(), log_n, &pre_lo, &pre_hi, &pre_h);
             if (rc) return rc;
             if ((rc = get_full_table(ctx, key + ":full", pre_lo, pre_hi, pre_h, 0, N, &pre_full))) return rc;
         } else {
             Fr gi = fe_inv(g);
             const std::string key = "cs:i:" + std::to_string(log_n) + ":" + fr_hex(g);
-            int rc = get_pow2l(ctx, key, gi, n_inv, log_n, &post_lo, &post_hi, &post_h);
+            int rc = evict_coset_tables(ctx, key, (size_t)N * sizeof(Fr));
+            if (rc) return rc;
+            rc = get_pow2l(ctx, key, gi, n_inv, log_n, &post_lo, &post_hi, &post_h);
             if (rc) return rc;
             if ((rc = get_full_table(ctx, key + ":full", post_lo, post_hi, post_h, 0, N, &post_full))) return rc;
         }
@@ -447,6 +532,34 @@ void msm_shape(typlonk_ctx* ctx, size_t m, uint32_t* c_out, uint32_t* w_out) {
     *w_out = (256 + c - 1) / c;
 }
 
+// Shape of the two-level (segmented) counting sort for an m-term MSM with c-bit windows: hb high bucket bits pick the
+// segment, the low lb <= 8 bits are sorted in LDS; a level-1 entry packs [i : ibits][j : 4 in table mode][sign][low : lb]
+// into 32 bits.  ok = the segmented sort can handle it (otherwise: plain MSMs use the atomic sort, table mode is not
+// available).
+struct SegShape {
+    uint32_t ibits = 0;
+    int hb = 0;
+    uint64_t nseg = 0, nblk = 0, nmat = 0;
+    bool ok = false;
+};
+SegShape msm_seg_shape(size_t m, uint32_t c, uint32_t W, uint32_t nsets, bool tables) {
+    SegShape sh;
+    uint32_t lgm = 0;
+    while (((uint64_t)1 << lgm) < m) ++lgm;
+    sh.ibits = tables ? std::max<uint32_t>(lgm, 1) : 23;
+    const int lb_max = tables ? std::min<int>(8, 32 - (int)sh.ibits - 5) : 8;
+    int hb = std::max<int>((int)c - 1 - lb_max, tables ? 0 : (int)lgm - 13);
+    sh.hb = std::max(0, std::min<int>(hb, (int)c - 1));
+    sh.nseg = (uint64_t)nsets << sh.hb;
+    sh.nblk = msm_segsort_blocks(m);
+    sh.nmat = sh.nseg * sh.nblk;
+    sh.ok = m <= (1u << 23) && lb_max >= 1 && sh.nseg * 4 <= 64 * 1024 && sh.nmat < (1ull << 31) && (!tables || W <= 16) &&
+            (uint64_t)W * m < (1ull << 31);
+    return sh;
+}
+// can a full-length MSM over a len-point SRS run in table mode with c-bit windows?  (the longest MSM is the worst case)
+bool msm_table_shape_ok(size_t len, uint32_t c, uint32_t T) { return msm_seg_shape(len, c, T, 1, true).ok; }
+
 // internal affine -> the C-ABI's arkworks form
 void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf) {
     uint32_t w[12];
@@ -490,7 +603,10 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     msm_shape(ctx, m, &c, &W);
     // fixed-base tables: every window reads its own pre-shifted copy of the base, so all windows share
     // one bucket set (plus a separate set for a thin top window) and no cross-window doublings remain
-    const bool tables = srs.table_T != 0 && m >= srs.len / 4 && srs.len <= (1u << 23) && !ctx->msm_legacy_sort;
+    // (typlonk_srs_precompute refuses shapes the table-mode sort cannot handle; the check here keeps a plain MSM
+    // possible should one slip through)
+    const bool tables = srs.table_T != 0 && m >= srs.len / 4 && srs.len <= (1u << 23) && !ctx->msm_legacy_sort &&
+                        msm_seg_shape(m, srs.table_c, srs.table_T, 1, true).ok;
     if (tables) {
         c = srs.table_c;
         W = srs.table_T;
@@ -545,18 +661,12 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
 
     // segmented sort shape: hb high bucket bits pick the segment, lb <= 8 low bits are sorted in LDS;
     // the level-1 entry packs [i : ibits][j : 4 in table mode][sign][low : lb] into 32 bits
-    uint32_t lgm = 0;
-    while (((uint64_t)1 << lgm) < m) ++lgm;
-    const uint32_t ibits = tables ? std::max<uint32_t>(lgm, 1) : 23;
-    const int lb_max = tables ? std::min<int>(8, 32 - (int)ibits - 5) : 8;
-    int hb = std::max<int>((int)c - 1 - lb_max, tables ? 0 : (int)lgm - 13);
-    hb = std::max(0, std::min<int>(hb, (int)c - 1));
-    const uint64_t nseg = (uint64_t)nsets << hb;
-    const uint64_t nblk = msm_segsort_blocks(m);
-    const uint64_t nmat = nseg * nblk;
-    const bool segsort = !ctx->msm_legacy_sort && m <= (1u << 23) && nseg * 4 <= 64 * 1024 && nmat < (1ull << 31) &&
-                         (!tables || W <= 16);
-    if (tables && !segsort) return fail(ctx, TYPLONK_ERR_LENGTH, "table-mode MSM shape not supported");
+    const SegShape seg = msm_seg_shape(m, c, W, nsets, tables);
+    const uint32_t ibits = seg.ibits;
+    const int hb = seg.hb;
+    const uint64_t nmat = seg.nmat;
+    const bool segsort = !ctx->msm_legacy_sort && seg.ok;
+    if (tables && !segsort) return fail(ctx, TYPLONK_ERR_LENGTH, "table-mode MSM shape not supported");  // unreachable
     if (segsort) {
         if ((rc = ensure(ctx, ws.blk_hist, nmat * 4))) return rc;
         if ((rc = ensure(ctx, ws.blk_base, (nmat + 1) * 4))) return rc;
@@ -741,8 +851,7 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
     }
     if (!count) return TYPLONK_OK;
     prof_begin(ctx);
-    const bool prof = ctx->profiling;
-    ctx->profiling = false;  // stage events are per-call; a batch interleaves two calls
+    ProfilingOff prof_off(ctx);  // stage events are per call
     const int lanes = std::max(1, std::min<int>(ctx->msm_inflight, typlonk_ctx::MSM_LANES));
     if (!ctx->batch_evt) HIPCHK(hipEventCreateWithFlags(&ctx->batch_evt, hipEventDisableTiming));
     // work already queued on the context's stream (e.g. the iNTT that produced the scalars) must be
@@ -770,7 +879,6 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
         const int r = msm_finish(ctx, ctx->ws[l]);
         if (!rc) rc = r;
     }
-    ctx->profiling = prof;
     return rc;
 }
 
@@ -791,6 +899,7 @@ const char* typlonk_strerror(int code) {
         case TYPLONK_ERR_HIP: return "HIP runtime error";
         case TYPLONK_ERR_OOM: return "device out of memory";
         case TYPLONK_ERR_RANGE: return "range outside device buffer";
+        case TYPLONK_ERR_UNSATISFIED: return "witness does not satisfy the circuit (r(zeta) != 0)";
         default: return "unknown error";
     }
 }
@@ -806,7 +915,9 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (hipSetDevice(device_ordinal) != hipSuccess) return TYPLONK_ERR_HIP;
     typlonk_ctx* ctx = new typlonk_ctx();
     ctx->device = device_ordinal;
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    // an ordinary (blocking) stream: ordered after work on the legacy default stream, where a caller that never
+    // created a stream (PyTorch-ROCm by default) produced the device-resident inputs of the *_devptr calls
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) != hipSuccess) {
         delete ctx;
         return TYPLONK_ERR_HIP;
     }
@@ -869,19 +980,23 @@ int typlonk_srs_load(typlonk_ctx* ctx, const uint64_t* xy, const uint8_t* inf, s
     HIPCHK(hipSetDevice(ctx->device));
     SrsEntry e;
     e.len = len;
+    DevGuard guard;
     HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * PT_WORDS * 4));
+    guard.add(e.d_points);
     if (len) {
         HIPCHK(hipMemcpy2DAsync(e.d_points, PT_WORDS * 4, xy, 96, 96, len, hipMemcpyHostToDevice, ctx->stream));
+        DevGuard flags;  // freed on every path out of this block
         uint8_t* d_inf = nullptr;
         if (inf) {
             HIPCHK(hipMalloc((void**)&d_inf, len));
+            flags.add(d_inf);
             HIPCHK(hipMemcpyAsync(d_inf, inf, len, hipMemcpyHostToDevice, ctx->stream));
         }
         launch_convert_points(e.d_points, d_inf, (uint64_t)len, ctx->stream);  // arkworks -> internal form
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (d_inf) HIPCHK(hipFree(d_inf));
     }
+    guard.dismiss();
     const uint32_t id = ctx->next_srs++;
     ctx->srs[id] = e;
     *srs_id = id;
@@ -922,7 +1037,9 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
     HIPCHK(hipSetDevice(ctx->device));
     SrsEntry e;
     e.len = len;
+    DevGuard guard;
     HIPCHK(hipMalloc((void**)&e.d_points, std::max<size_t>(len, 1) * PT_WORDS * 4));
+    guard.add(e.d_points);
     if (len) {
         Fr s;
         memcpy(s.v, secret, sizeof(s.v));
@@ -930,6 +1047,7 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
+    guard.dismiss();
     const uint32_t id = ctx->next_srs++;
     ctx->srs[id] = e;
     *srs_id = id;
@@ -946,12 +1064,19 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     if (e.len == 0 || e.len > (1u << 23)) return fail(ctx, TYPLONK_ERR_LENGTH, "tables need 1 <= len <= 2^23");
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t T = (256 + window_bits - 1) / window_bits;
+    // the table-mode sort of a full-length MSM must be possible, otherwise every later MSM over this SRS would fail
+    // where the plain path works: refuse here and leave the SRS as it is (e.g. len > 2^22 with 20-bit windows)
+    if (!msm_table_shape_ok(e.len, window_bits, T))
+        return fail(ctx, TYPLONK_ERR_LENGTH, "fixed-base tables with this window are not supported for an SRS of this length");
     uint32_t* big = nullptr;
     HIPCHK(hipMalloc((void**)&big, (size_t)T * e.len * PT_WORDS * 4));
+    DevGuard guard;
+    guard.add(big);
     HIPCHK(hipMemcpyAsync(big, e.d_points, e.len * PT_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
     launch_srs_tables(big, (uint64_t)e.len, window_bits, T, ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    guard.dismiss();
     HIPCHK(hipFree(e.d_points));
     e.d_points = big;
     e.table_c = window_bits;
@@ -1089,30 +1214,28 @@ int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5]
         if (!b || b->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "circuit polynomial shorter than n");
     CircuitEntry e;
     e.log_n = log_n;
+    DevGuard guard;
     HIPCHK(hipMalloc((void**)&e.ext, 9 * n4 * sizeof(Fr)));
+    guard.add(e.ext);
     HIPCHK(hipMalloc((void**)&e.coef, 8 * n * sizeof(Fr)));
+    guard.add(e.coef);
     HIPCHK(hipMalloc((void**)&e.sig_ev, 3 * n * sizeof(Fr)));
+    guard.add(e.sig_ev);
     for (int k = 0; k < 8; ++k)
         HIPCHK(hipMemcpyAsync(e.coef + (uint64_t)k * n, in[k]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(e.sig_ev, e.coef + 5 * n, 3 * n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
-    const bool prof = ctx->profiling;
-    ctx->profiling = false;
+    ProfilingOff prof_off(ctx);  // stage events are per call
     int rc = TYPLONK_OK;
     const Fr ninv = fe_inv(fr_from_u64(n));
     for (int k = 0; k < 9 && !rc; ++k)
         rc = quotient_extend(ctx, e.ext + (uint64_t)k * n4, k < 8 ? in[k]->d : nullptr, &ninv, n, log_n + 2);
     for (int k = 0; k < 3 && !rc; ++k) rc = ntt_run(ctx, e.sig_ev + (uint64_t)k * n, log_n, 0, nullptr, /*sync=*/false);
-    ctx->profiling = prof;
     if (!rc) {
         hipError_t he = hipStreamSynchronize(ctx->stream);
         if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
     }
-    if (rc) {
-        (void)hipFree(e.ext);
-        (void)hipFree(e.coef);
-        (void)hipFree(e.sig_ev);
-        return rc;
-    }
+    if (rc) return rc;
+    guard.dismiss();
     const uint32_t id = ctx->next_circuit++;
     ctx->circuits[id] = e;
     *circuit_id = id;
@@ -1161,15 +1284,13 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     hipStream_t s = ctx->stream;
     Fr g;
     const uint64_t* g_limbs = quotient_coset_g(&g);
-    const bool prof = ctx->profiling;
-    ctx->profiling = false;
+    ProfilingOff prof_off(ctx);  // stage events are per call
     const Fr ninv = fe_inv(fr_from_u64(n));
     for (int k = 0; k < (cached ? 5 : 14) && !rc; ++k) {
         if (k == 4 && !has_pi) continue;
         rc = quotient_extend(ctx, ext + (uint64_t)k * n4, k < 13 ? in[k]->d : nullptr, &ninv, n, log4);
     }
     if (rc) {
-        ctx->profiling = prof;
         return rc;
     }
     QuotientArgs qa{};
@@ -1187,7 +1308,6 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
         const Fr w4 = fr_domain_root(log4);
         rc = get_pow2l(ctx, "tw:f:" + std::to_string(log4), w4, Fr::one(), log4, &lo, &hi, &qa.w_h);
         if (rc) {
-            ctx->profiling = prof;
             return rc;
         }
         qa.w_lo = lo.d;
@@ -1212,7 +1332,6 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     launch_quotient_pointwise(qa, s);
     HIPCHK(hipGetLastError());
     rc = ntt_run(ctx, t_out->d, log4, 1, g_limbs, /*sync=*/false);
-    ctx->profiling = prof;
     return rc;
 }
 
@@ -1423,25 +1542,27 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     for (int i = 0; i < 6; ++i) { p->q[i] = c; c += n; }
     p->r = c;
     hipStream_t s = ctx->stream;
-    const bool prof = ctx->profiling;
-    ctx->profiling = false;
+    ProfilingOff prof_off(ctx);  // stage events are per call
     // a, b, c = interpolate(columns) (proof.rs:50); the column values themselves are kept for round 2
     // (proof.rs:113-115 recomputes them with three forward FFTs)
+    auto d2d = [&](Fr* dst, const Fr* src) -> int {
+        const hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
+        return e == hipSuccess ? TYPLONK_OK : fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(e));
+    };
     for (int i = 0; i < 3 && !rc; ++i) {
-        hipMemcpyAsync(p->ev[i], wire_evals[i]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(p->co[i], wire_evals[i]->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
+        if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
+        if ((rc = d2d(p->co[i], wire_evals[i]->d))) break;
         rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false);
     }
     p->has_pi = pi_evals != nullptr;  // NULL: public inputs [0] -> the zero polynomial
     if (!rc && p->has_pi) {
-        hipMemcpyAsync(p->pi, pi_evals->d, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
-        rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
+        rc = d2d(p->pi, pi_evals->d);
+        if (!rc) rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
     }
     if (!rc) {
         const size_t m[3] = {n, n, n};
         rc = prover_commit_batch(p, p->co, m, 3, &commit_xy[0][0], commit_inf);  // round1, proof.rs:107-110
     }
-    ctx->profiling = prof;
     if (rc) {
         delete p;
         return rc;
@@ -1470,8 +1591,7 @@ int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint6
     const typlonk_buf* wp[3] = {&wb[0], &wb[1], &wb[2]};
     const typlonk_buf* sp[3] = {&sb[0], &sb[1], &sb[2]};
     typlonk_buf zb{p->z, n};
-    const bool prof = ctx->profiling;
-    ctx->profiling = false;
+    ProfilingOff prof_off(ctx);  // stage events are per call
     int rc = typlonk_grand_product_dev(ctx, wp, sp, beta, gamma, cosets, p->log_n, &zb);  // proof.rs:119-120
     if (!rc) rc = ntt_run(ctx, p->z, p->log_n, 1, nullptr, false);                          // :127-128
     if (!rc) {
@@ -1479,7 +1599,6 @@ int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint6
         const size_t m[1] = {n};
         rc = prover_commit_batch(p, polys, m, 1, z_xy, z_inf);                              // :129
     }
-    ctx->profiling = prof;
     if (!rc) p->round = 2;
     return rc;
 }
@@ -1502,8 +1621,7 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
     Fr al, ze;
     memcpy(al.v, alpha, 32);
     memcpy(ze.v, zeta, 32);
-    const bool prof = ctx->profiling;
-    ctx->profiling = false;
+    ProfilingOff prof_off(ctx);  // stage events are per call
     int rc;
     // ---- quotient (proof.rs:139-145) ----
     {
@@ -1613,8 +1731,14 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
             for (int i = 0; i < 6; ++i) memcpy(out->evals[i], ev[i].v, 32);
         }
     }
-    ctx->profiling = prof;
-    if (!rc) p->round = 3;
+    if (!rc) {
+        p->round = 3;
+        // the verifier's check (proof.rs:234-235).  A witness that violates a gate makes the reference panic in
+        // vanishes() (:321, :361); here the division by Z_H leaves a remainder the slices drop, and r(zeta) != 0
+        // is how that shows.  Everything in `out` is filled; the caller learns the proof cannot verify.
+        if (!ev[5].is_zero())
+            return fail(ctx, TYPLONK_ERR_UNSATISFIED, "r(zeta) != 0: the witness does not satisfy the circuit (proof.rs:234-235)");
+    }
     return rc;
 }
 }  // namespace
@@ -1636,8 +1760,7 @@ int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlon
     if (p->round != 3 || !p->evals_only) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "round4_batched must follow round3_evals");
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = p->n;
-    const bool prof = ctx->profiling;
-    ctx->profiling = false;
+    ProfilingOff prof_off(ctx);  // stage events are per call
     // F = a + v b + v^2 c + v^3 Z + v^4 r; division by (X - zeta) is linear, so its witness is
     // sum_i v^i W_i of the six-opening proof
     LincombArgs la{};
@@ -1675,7 +1798,6 @@ int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlon
             p->round = 4;
         }
     }
-    ctx->profiling = prof;
     return rc;
 }
 
