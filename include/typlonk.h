@@ -75,11 +75,11 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
 int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_t count, uint64_t* xy, uint8_t* inf);
 /* Optional fixed-base precomputation (the SRS is immutable per circuit, plonk/src/lib.rs:22): builds the
  * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM, c = window_bits in
- * 16..20; 20 is the balanced choice: its top window still has 15 bits; a (len, window_bits) pair whose
- * table-mode sort shape is not supported -- len > 2^22 with 20 bits -- is refused with TYPLONK_ERR_LENGTH and
- * the SRS stays usable without tables).  Later MSMs of at least len/4
+ * 16..20; 20 is the balanced choice: its top window still has 15 bits).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
- * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point. */
+ * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point.
+ * An MSM length the table-mode sort cannot handle (more than 2^22 terms with 20-bit windows) silently takes the
+ * plain path over the same SRS: precomputation never turns a valid MSM into an error. */
 int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bits);
 /* Multi-GPU: declare that this entry holds bases [first_index, first_index + len) of a total_len-point SRS
  * (one process per GPU, each with its own slice).  Every MSM / prover call on it then takes the FULL

@@ -402,3 +402,48 @@ def test_shard_argument_errors(ctx):
     exp = O.g1_mul(O.G1, 3 * sum(pow(5, i, O.R) for i in range(20, 30)) % O.R)
     assert g1_unpack_one(out, inf) == exp
     ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 5, 8])
+def test_chunked_pipeline_gives_identical_results(built, chunks, monkeypatch):
+    """A stand-alone MSM is cut into chunks of terms that add into the same buckets (sort of chunk k + 1 overlapping
+    the accumulation of chunk k, capi.hip msm_enqueue).  Every chunk count -- forced through TYPLONK_MSM_CHUNKS --
+    gives the bit-identical point, with and without fixed-base tables, for uniform and adversarial scalars (heavy
+    buckets cross chunk boundaries), full and ragged lengths, and on an SRS shard."""
+    import typlonk_amd
+    from oracle import coracle as CO
+
+    monkeypatch.setenv("TYPLONK_MSM_CHUNKS", str(chunks))
+    c2 = typlonk_amd.Context(0)
+    try:
+        length = (1 << 16) + 77
+        secret = 0xABCDEF0123
+        s_limbs = np.array(O.fr_to_mont_limbs(secret), dtype=np.uint64)
+        plain = c2.srs_generate(s_limbs, length)
+        tab = c2.srs_generate(s_limbs, length)
+        c2.srs_precompute(tab, 20)
+        shard = c2.srs_generate(s_limbs, length - 1000, start=1000)
+        c2.srs_set_shard(shard, 1000, length)
+        rng = np.random.default_rng(4242 + chunks)
+        for m in (length, length - 3, 40000, 4097 * chunks + 1):
+            for kind in ("uniform", "mixed", "ones"):
+                if kind == "uniform":
+                    sc = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2
+                    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+                elif kind == "mixed":
+                    sc = _mixed_scalars(rng, m)
+                else:
+                    sc = np.tile(np.array(O.fr_to_mont_limbs(1), dtype=np.uint64), (m, 1))
+                ps = CO.poly_eval(sc, s_limbs)                      # commit(p) == [p(s)]G, kzg/src/lib.rs:102-105
+                exp_xy, exp_inf = CO.g1_mul_generator(ps)
+                for h in (plain, tab):
+                    got, ginf = c2.msm(h, sc)
+                    assert (got == exp_xy).all() and ginf == exp_inf, (chunks, m, kind, h == tab)
+                # the shard's partial sum = the full sum minus the first 1000 terms
+                part, pinf = c2.msm(shard, sc)
+                head, hinf = c2.msm(plain, sc[:1000])
+                from typlonk_amd.capi import g1_sum_host
+                fxy, finf = g1_sum_host(np.stack([part, head]), np.array([pinf, hinf], dtype=np.uint8))
+                assert (fxy == exp_xy).all() and finf == exp_inf, (chunks, m, kind, "shard")
+    finally:
+        c2.close()

@@ -37,6 +37,10 @@ def hipcc_path() -> str:
 
 
 HIP_UNITS = ["capi.hip", "ntt_kernels.hip", "msm_sort.hip", "msm_accum.hip", "msm_reduce.hip", "srs_gen.hip", "quotient.hip", "plonk_ops.hip"]
+# per-unit flags (none in use).  -DFQ30_ASM_CHAIN for msm_accum.hip was measured: the micro-benchmark's mixed-add ceiling
+# rises 7.0 -> 7.3-7.5 G/s (profiles/r02_ubench2_chain.txt) but the real accumulation kernel does not move in a same-box
+# A/B (profiles/r02_ab_chain_ntt.txt: 1.85-1.90 ms either way), so the compiler-scheduled form stays.
+UNIT_FLAGS: dict[str, list[str]] = {}
 
 
 def build_hip(force: bool = False) -> str:
@@ -54,7 +58,7 @@ def build_hip(force: bool = False) -> str:
         obj = os.path.join(objdir, u.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *UNIT_FLAGS.get(u, []), "-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(_run, jobs))

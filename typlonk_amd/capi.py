@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtyplonk_hip.so")
+# TYPLONK_LIB_PATH: another build of the same library (same-box A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("TYPLONK_LIB_PATH") or os.path.join(_HERE, "libtyplonk_hip.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RANGE, ERR_UNSATISFIED = -1, -2, -3, -4, -5, -6, -7, -8

@@ -67,10 +67,22 @@ struct ProfStage {
 // normalisation) and kernel tail with the next one's sort + accumulate.
 constexpr size_t HOST_WIN_POINTS = 32 * 2 * RC_NB;  // up to 32 bucket sets x {rows, columns} x RC_NB bit planes
 
+// Outputs of the bucket sort of one chunk of terms; a workspace owns two sets so that the sort of chunk k + 1 can run
+// (on the workspace's side stream) while chunk k is being accumulated.
+struct SortBufs {
+    DevBuf keys, sorted, counts, offsets, cursor, blocksums, order, ohist, blk_hist, blk_base, heavy, tasks, hpart;
+    std::vector<DevBuf*> all() {
+        return {&keys, &sorted, &counts, &offsets, &cursor, &blocksums, &order, &ohist, &blk_hist, &blk_base, &heavy, &tasks, &hpart};
+    }
+};
+constexpr int MSM_MAX_CHUNKS = 8;
+
 struct MsmWs {
-    DevBuf keys, sorted, counts, offsets, cursor, blocksums, buckets, part_a, part_b, order, ohist, blk_hist, blk_base, heavy, tasks,
-        hpart, rc_sums, rc_bits, rc_out;
+    SortBufs sb[2];
+    DevBuf buckets, part_a, part_b, rc_sums, rc_bits, rc_out;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;     // sorts of the chunks after the first (created on first use)
+    hipEvent_t ev_in = nullptr, ev_sorted[MSM_MAX_CHUNKS] = {}, ev_acc[MSM_MAX_CHUNKS] = {};
     uint32_t* host_wins = nullptr;  // pinned, HOST_WIN_POINTS x 48 words
     bool pending = false;
     uint32_t W = 0, c = 0;
@@ -117,6 +129,7 @@ struct typlonk_ctx {
     std::vector<ProfStage> prof;
     std::vector<std::pair<const char*, float>> prof_result;
     int msm_c_override = 0;
+    int msm_chunks = 0;            // TYPLONK_MSM_CHUNKS: chunks of a stand-alone MSM (0 = choose by length)
     bool ntt_full_tables = true;   // TYPLONK_NTT_FULL_TABLES=0: compose twiddles / coset powers from two-level tables
     uint32_t ntt_full_max_log = 24;
     bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
@@ -596,7 +609,7 @@ G1Xyzz unpack_xyzz(const uint32_t* p) {
 // Launch every kernel of one m-term MSM (m > 0, validated by the caller) on `stream` using workspace
 // `ws`, ending with the asynchronous copy of the W window sums into ws.host_wins.
 int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry& srs, const Fr* d_scalars, size_t m,
-                uint64_t* out_xy, uint8_t* out_inf) {
+                uint64_t* out_xy, uint8_t* out_inf, bool standalone) {
     ws.stream = stream;
     if (!ws.host_wins) HIPCHK(hipHostMalloc((void**)&ws.host_wins, HOST_WIN_POINTS * 192));
     uint32_t c, W;
@@ -622,85 +635,121 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     const uint32_t digit_v = tables ? 0u : top_v;
     const uint64_t nb = (uint64_t)nsets * B;
     const uint64_t nb_used = nb;
-    const uint64_t total = (uint64_t)W * m;
-    if (total >= (1ull << 31)) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM too large for 32-bit entry indices");
+    if ((uint64_t)W * m >= (1ull << 31)) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM too large for 32-bit entry indices");
     const uint32_t L = std::min<uint32_t>(MSM_SEG, B);
     const uint32_t npw = B / L;
     const uint32_t nodes = nsets * npw;
     const uint32_t scan_blocks = (uint32_t)((nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
 
+    // Chunks of terms.  A stand-alone MSM (nothing else in flight to hide behind) is cut into chunks that all add into
+    // the SAME buckets: while chunk k is accumulated on the MSM's stream, chunk k + 1 is sorted on the workspace's side
+    // stream, so only the first chunk's sort (and the last one's reduction) stay exposed.  Later chunks start from the
+    // stored buckets (192 B read + written per bucket and chunk -- noise next to the additions).  Bit-identical
+    // results: group addition is commutative and the output is the canonical affine point.
+    uint32_t nch = 1;
+    if (standalone && !ctx->msm_legacy_sort) {
+        // measured (tools/msm_chunks.py, profiles/r02_msm_chunks.jsonl): the overlapped sort is not free -- it competes
+        // with the accumulation for issue slots -- so two chunks are the best split at 2^20 terms (2.78 -> 2.73 ms) and
+        // below 2^20 one chunk wins
+        nch = ctx->msm_chunks ? (uint32_t)ctx->msm_chunks : (m >= (1u << 20) ? 2u : 1u);
+        while (nch > 1 && m / nch < 4096) --nch;
+    }
+    const size_t step = (m + nch - 1) / nch;
+    hipStream_t s = ws.stream;
     int rc;
-    if ((rc = ensure(ctx, ws.keys, total * 4))) return rc;
-    if ((rc = ensure(ctx, ws.sorted, total * 4))) return rc;
-    if ((rc = ensure(ctx, ws.counts, nb * 4))) return rc;
-    if ((rc = ensure(ctx, ws.offsets, (nb + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ws.cursor, nb * 4))) return rc;
-    if ((rc = ensure(ctx, ws.blocksums, (size_t)scan_blocks * 4))) return rc;
+    if (nch > 1) {
+        if (!ws.side) HIPCHK(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
+        if (!ws.ev_in) HIPCHK(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming));
+        for (uint32_t k = 0; k < nch; ++k) {
+            if (!ws.ev_sorted[k]) HIPCHK(hipEventCreateWithFlags(&ws.ev_sorted[k], hipEventDisableTiming));
+            if (!ws.ev_acc[k]) HIPCHK(hipEventCreateWithFlags(&ws.ev_acc[k], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ws.ev_in, s));  // the scalars (and whatever produced them) are ordered on s
+        HIPCHK(hipStreamWaitEvent(ws.side, ws.ev_in, 0));
+    }
     if ((rc = ensure(ctx, ws.buckets, nb * 192))) return rc;
-    if ((rc = ensure(ctx, ws.order, nb * 4))) return rc;
-    if ((rc = ensure(ctx, ws.ohist, 514 * 4))) return rc;
-    // heavy-bucket splitting: cap = entries one thread may sum; at most total/cap heavy buckets/tasks
-    const uint32_t cap = (uint32_t)std::max<uint64_t>(512, 4 * ((total + nb_used - 1) / nb_used));
-    const uint64_t max_tasks = total / cap + 2;
-    if ((rc = ensure(ctx, ws.heavy, max_tasks * 12))) return rc;
-    if ((rc = ensure(ctx, ws.tasks, max_tasks * 8))) return rc;
-    if ((rc = ensure(ctx, ws.hpart, max_tasks * 192))) return rc;
     if ((rc = ensure(ctx, ws.part_a, (size_t)nodes * 192))) return rc;
     if ((rc = ensure(ctx, ws.part_b, (size_t)nodes * 192))) return rc;
-
-    uint32_t* keys = (uint32_t*)ws.keys.p;
-    uint32_t* sorted = (uint32_t*)ws.sorted.p;
-    uint32_t* counts = (uint32_t*)ws.counts.p;
-    uint32_t* offsets = (uint32_t*)ws.offsets.p;
-    uint32_t* cursor = (uint32_t*)ws.cursor.p;
-    uint32_t* blocksums = (uint32_t*)ws.blocksums.p;
     uint32_t* buckets = (uint32_t*)ws.buckets.p;
     uint32_t* pa = (uint32_t*)ws.part_a.p;
     uint32_t* pb = (uint32_t*)ws.part_b.p;
-    hipStream_t s = ws.stream;
 
-    // segmented sort shape: hb high bucket bits pick the segment, lb <= 8 low bits are sorted in LDS;
-    // the level-1 entry packs [i : ibits][j : 4 in table mode][sign][low : lb] into 32 bits
-    const SegShape seg = msm_seg_shape(m, c, W, nsets, tables);
-    const uint32_t ibits = seg.ibits;
-    const int hb = seg.hb;
-    const uint64_t nmat = seg.nmat;
-    const bool segsort = !ctx->msm_legacy_sort && seg.ok;
-    if (tables && !segsort) return fail(ctx, TYPLONK_ERR_LENGTH, "table-mode MSM shape not supported");  // unreachable
-    if (segsort) {
-        if ((rc = ensure(ctx, ws.blk_hist, nmat * 4))) return rc;
-        if ((rc = ensure(ctx, ws.blk_base, (nmat + 1) * 4))) return rc;
-        if ((rc = ensure(ctx, ws.blocksums, (size_t)((nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks) * 4))) return rc;
-        blocksums = (uint32_t*)ws.blocksums.p;
-        StageTimer st(ctx, "msm_sort", s);
-        launch_msm_segsort(d_scalars, (uint64_t)m, c, W, digit_v, (uint32_t)hb, ibits, tables ? (uint32_t)srs.len : 0u,
-                           tables ? nsets : 0u, (uint32_t*)ws.blk_hist.p, (uint32_t*)ws.blk_base.p, blocksums, keys,
-                           counts, offsets, sorted, s);
-    } else {
-        {
-            StageTimer st(ctx, "msm_digits", s);
-            HIPCHK(hipMemsetAsync(counts, 0, nb * 4, s));
-            launch_msm_digits(d_scalars, (uint64_t)m, c, W, top_v, keys, counts, s);
+    for (uint32_t k = 0; k < nch; ++k) {
+        const size_t off = (size_t)k * step;
+        if (off >= m) break;
+        const size_t mk = std::min(step, m - off);
+        const Fr* sc = d_scalars + off;
+        const uint32_t* pts = srs.d_points + off * PT_WORDS;  // chunk-local term index i -> base off + i (table t: + t*len)
+        SortBufs& sb = ws.sb[k & 1];
+        hipStream_t ss = (nch > 1 && k > 0) ? ws.side : s;   // the first sort has nothing to overlap with
+        if (nch > 1 && k >= 2 && ss != s) HIPCHK(hipStreamWaitEvent(ss, ws.ev_acc[k - 2], 0));  // sb[k & 1] is free again
+        const uint64_t total = (uint64_t)W * mk;
+        if ((rc = ensure(ctx, sb.keys, total * 4))) return rc;
+        if ((rc = ensure(ctx, sb.sorted, total * 4))) return rc;
+        if ((rc = ensure(ctx, sb.counts, nb * 4))) return rc;
+        if ((rc = ensure(ctx, sb.offsets, (nb + 1) * 4))) return rc;
+        if ((rc = ensure(ctx, sb.cursor, nb * 4))) return rc;
+        if ((rc = ensure(ctx, sb.blocksums, (size_t)scan_blocks * 4))) return rc;
+        if ((rc = ensure(ctx, sb.order, nb * 4))) return rc;
+        if ((rc = ensure(ctx, sb.ohist, 514 * 4))) return rc;
+        // heavy-bucket splitting: cap = entries one thread may sum; at most total/cap heavy buckets/tasks
+        const uint32_t cap = (uint32_t)std::max<uint64_t>(512, 4 * ((total + nb_used - 1) / nb_used));
+        const uint64_t max_tasks = total / cap + 2;
+        if ((rc = ensure(ctx, sb.heavy, max_tasks * 12))) return rc;
+        if ((rc = ensure(ctx, sb.tasks, max_tasks * 8))) return rc;
+        if ((rc = ensure(ctx, sb.hpart, max_tasks * 192))) return rc;
+        uint32_t* keys = (uint32_t*)sb.keys.p;
+        uint32_t* sorted = (uint32_t*)sb.sorted.p;
+        uint32_t* counts = (uint32_t*)sb.counts.p;
+        uint32_t* offsets = (uint32_t*)sb.offsets.p;
+        uint32_t* cursor = (uint32_t*)sb.cursor.p;
+        uint32_t* blocksums = (uint32_t*)sb.blocksums.p;
+
+        // segmented sort shape: hb high bucket bits pick the segment, lb <= 8 low bits are sorted in LDS;
+        // the level-1 entry packs [i : ibits][j : 4 in table mode][sign][low : lb] into 32 bits
+        const SegShape seg = msm_seg_shape(mk, c, W, nsets, tables);
+        const bool segsort = !ctx->msm_legacy_sort && seg.ok;
+        if (tables && !segsort) return fail(ctx, TYPLONK_ERR_LENGTH, "table-mode MSM shape not supported");  // unreachable
+        if (segsort) {
+            if ((rc = ensure(ctx, sb.blk_hist, seg.nmat * 4))) return rc;
+            if ((rc = ensure(ctx, sb.blk_base, (seg.nmat + 1) * 4))) return rc;
+            if ((rc = ensure(ctx, sb.blocksums, (size_t)((seg.nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks) * 4))) return rc;
+            blocksums = (uint32_t*)sb.blocksums.p;
+            StageTimer st(ctx, "msm_sort", ss);
+            launch_msm_segsort(sc, (uint64_t)mk, c, W, digit_v, (uint32_t)seg.hb, seg.ibits, tables ? (uint32_t)srs.len : 0u,
+                               tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums, keys,
+                               counts, offsets, sorted, ss);
+        } else {
+            {
+                StageTimer st(ctx, "msm_digits", ss);
+                HIPCHK(hipMemsetAsync(counts, 0, nb * 4, ss));
+                launch_msm_digits(sc, (uint64_t)mk, c, W, top_v, keys, counts, ss);
+            }
+            {
+                StageTimer st(ctx, "msm_scan", ss);
+                launch_scan(counts, nb, blocksums, offsets, cursor, ss);
+            }
+            {
+                StageTimer st(ctx, "msm_scatter", ss);
+                launch_msm_scatter(keys, (uint64_t)mk, total, cursor, sorted, ss);
+            }
         }
         {
-            StageTimer st(ctx, "msm_scan", s);
-            launch_scan(counts, nb, blocksums, offsets, cursor, s);
+            StageTimer st(ctx, "msm_order", ss);
+            launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.order.p,
+                                (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, ss);
+        }
+        if (ss != s) {
+            HIPCHK(hipEventRecord(ws.ev_sorted[k], ss));
+            HIPCHK(hipStreamWaitEvent(s, ws.ev_sorted[k], 0));
         }
         {
-            StageTimer st(ctx, "msm_scatter", s);
-            launch_msm_scatter(keys, (uint64_t)m, total, cursor, sorted, s);
+            StageTimer st(ctx, "msm_accum", s);
+            launch_msm_accum(pts, offsets, sorted, (const uint32_t*)sb.order.p, (uint32_t)nb_used, cap, /*init=*/k > 0, buckets, s);
+            launch_msm_heavy(pts, sorted, (const uint32_t*)sb.ohist.p, (const uint32_t*)sb.heavy.p,
+                             (const uint32_t*)sb.tasks.p, (uint32_t*)sb.hpart.p, buckets, s);
         }
-    }
-    {
-        StageTimer st(ctx, "msm_order", s);
-        launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)ws.ohist.p, (uint32_t*)ws.order.p,
-                            (uint32_t*)ws.heavy.p, (uint32_t*)ws.tasks.p, s);
-    }
-    {
-        StageTimer st(ctx, "msm_accum", s);
-        launch_msm_accum(srs.d_points, offsets, sorted, (const uint32_t*)ws.order.p, (uint32_t)nb_used, cap, buckets, s);
-        launch_msm_heavy(srs.d_points, sorted, (const uint32_t*)ws.ohist.p, (const uint32_t*)ws.heavy.p,
-                         (const uint32_t*)ws.tasks.p, (uint32_t*)ws.hpart.p, buckets, s);
+        if (nch > 1 && k + 2 < nch) HIPCHK(hipEventRecord(ws.ev_acc[k], s));
     }
     // reduce one group of `nwin` equally sized windows of `Bw` buckets starting at bucket `first`; the
     // window sums land in ws.host_wins[slot ...]
@@ -833,7 +882,7 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     if (!d_scalars) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null scalars");
     if (!ptr_is_local) d_scalars += off;
     m = ml;
-    if ((rc = msm_enqueue(ctx, ctx->ws[0], ctx->stream, *srs, d_scalars, m, out_xy, out_inf))) return rc;
+    if ((rc = msm_enqueue(ctx, ctx->ws[0], ctx->stream, *srs, d_scalars, m, out_xy, out_inf, /*standalone=*/true))) return rc;
     if ((rc = msm_finish(ctx, ctx->ws[0]))) return rc;
     prof_collect(ctx);
     return TYPLONK_OK;
@@ -873,7 +922,7 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
             continue;
         }
         rc = msm_enqueue(ctx, ws, l ? ctx->lane[l] : ctx->stream, *srs, (const Fr*)d_scalars[k] + off, ml,
-                         out_xy + 12 * k, out_inf + k);
+                         out_xy + 12 * k, out_inf + k, /*standalone=*/count == 1);
     }
     for (int l = 0; l < typlonk_ctx::MSM_LANES; ++l) {
         const int r = msm_finish(ctx, ctx->ws[l]);
@@ -929,6 +978,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_SORT")) ctx->msm_legacy_sort = (strcmp(e, "atomic") == 0);
     if (const char* e = getenv("TYPLONK_MSM_REDUCE")) ctx->msm_tree_reduce = (strcmp(e, "running") == 0);
     if (const char* e = getenv("TYPLONK_MSM_INFLIGHT")) ctx->msm_inflight = atoi(e);
+    if (const char* e = getenv("TYPLONK_MSM_CHUNKS")) ctx->msm_chunks = std::max(0, std::min(atoi(e), MSM_MAX_CHUNKS));
     if (const char* e = getenv("TYPLONK_NTT_FULL_TABLES")) ctx->ntt_full_tables = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_NTT_FULL_MAX_LOG")) ctx->ntt_full_max_log = (uint32_t)atoi(e);
     *out = ctx;
@@ -949,11 +999,16 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
     for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
     for (MsmWs& ws : ctx->ws) {
-        for (DevBuf* b : {&ws.keys, &ws.sorted, &ws.counts, &ws.offsets, &ws.cursor, &ws.blocksums, &ws.buckets, &ws.part_a,
-                          &ws.part_b, &ws.order, &ws.ohist, &ws.blk_hist, &ws.blk_base, &ws.heavy, &ws.tasks, &ws.hpart,
-                          &ws.rc_sums, &ws.rc_bits, &ws.rc_out})
-            release(*b);
+        for (SortBufs& sb : ws.sb)
+            for (DevBuf* b : sb.all()) release(*b);
+        for (DevBuf* b : {&ws.buckets, &ws.part_a, &ws.part_b, &ws.rc_sums, &ws.rc_bits, &ws.rc_out}) release(*b);
         if (ws.host_wins) (void)hipHostFree(ws.host_wins);
+        if (ws.side) (void)hipStreamDestroy(ws.side);
+        if (ws.ev_in) (void)hipEventDestroy(ws.ev_in);
+        for (hipEvent_t e : ws.ev_sorted)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ws.ev_acc)
+            if (e) (void)hipEventDestroy(e);
     }
     for (hipStream_t l : ctx->lane)
         if (l) (void)hipStreamDestroy(l);
@@ -1064,9 +1119,11 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     if (e.len == 0 || e.len > (1u << 23)) return fail(ctx, TYPLONK_ERR_LENGTH, "tables need 1 <= len <= 2^23");
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t T = (256 + window_bits - 1) / window_bits;
-    // the table-mode sort of a full-length MSM must be possible, otherwise every later MSM over this SRS would fail
-    // where the plain path works: refuse here and leave the SRS as it is (e.g. len > 2^22 with 20-bit windows)
-    if (!msm_table_shape_ok(e.len, window_bits, T))
+    // An MSM whose length has no table-mode sort shape (m > 2^22 with 20-bit windows: 23 index bits leave too few low
+    // bucket bits for the LDS level of the sort) simply takes the plain path over table 0, which IS the SRS
+    // (msm_enqueue) -- a set-up call that is supposed to be speed-only never turns a valid MSM into an error.  Only a
+    // window for which not even the shortest table-mode MSM (len / 4 terms) could be sorted is refused.
+    if (!msm_table_shape_ok(std::max<size_t>(e.len / 4, 1), window_bits, T))
         return fail(ctx, TYPLONK_ERR_LENGTH, "fixed-base tables with this window are not supported for an SRS of this length");
     uint32_t* big = nullptr;
     HIPCHK(hipMalloc((void**)&big, (size_t)T * e.len * PT_WORDS * 4));

@@ -191,6 +191,17 @@ TY_HD Fq30 fq30_sqr_split(const Fq30& a) {
 #define FQ30_MAC_CC_VS(acc, hi, a, b) FQ30_MAC_CC_VV(acc, hi, a, b)
 #endif
 
+// acc += a * b.  -DFQ30_ASM_CHAIN (experiment, tools/ubench2.hip) pins every mad of a column into ONE dependent
+// chain that starts from the shifted carry, so the compiler cannot give the column a fresh accumulator and merge the
+// carry with a separate 64-bit add.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FQ30_ASM_CHAIN)
+#define FQ30_MAD_VV(acc, a, b) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
+#define FQ30_MAD_VS(acc, a, b) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(b) : "vcc")
+#else
+#define FQ30_MAD_VV(acc, a, b) ((acc) += (uint64_t)(a) * (b))
+#define FQ30_MAD_VS(acc, a, b) ((acc) += (uint64_t)(a) * (b))
+#endif
+
 // capture schedule (tools/fq30_fused_bounds.py): in columns 11..14 the product terms from index `FIRST` on,
 // and the closing m_k * p_0 of columns 10..12
 TY_HD constexpr bool fq30_fused_wide_col(int k) { return k >= 10 && k <= 14; }
@@ -213,14 +224,14 @@ TY_HD Fq30 fq30_mulsqr_fused(const Fq30& a, const Fq30& b) {
         const bool wide = fq30_fused_wide_col(k);
         // reduction terms of this column: m_i p_(k-i), i < k (first half) / i >= k - 12 (second half)
 #pragma unroll
-        for (int i = (k > 12 ? k - 12 : 0); i < (k < 13 ? k : 13); ++i) acc += (uint64_t)m[i] * fq30_kp(1, k - i);
+        for (int i = (k > 12 ? k - 12 : 0); i < (k < 13 ? k : 13); ++i) FQ30_MAD_VS(acc, m[i], fq30_kp(1, k - i));
         // product terms
         if (k < 25) {
             int idx = 0;
             const int lo = (k > 12 ? k - 12 : 0), hi_i = (k < 12 ? k : 12);
             if (SQR) {
                 if ((k & 1) == 0) {
-                    acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+                    FQ30_MAD_VV(acc, a.v[k / 2], a.v[k / 2]);
                     ++idx;
                 }
 #pragma unroll
@@ -228,7 +239,7 @@ TY_HD Fq30 fq30_mulsqr_fused(const Fq30& a, const Fq30& b) {
                     if (wide && k >= 11 && idx >= FIRST) {
                         FQ30_MAC_CC_VV(acc, hi, d[i], a.v[k - i]);
                     } else {
-                        acc += (uint64_t)d[i] * a.v[k - i];
+                        FQ30_MAD_VV(acc, d[i], a.v[k - i]);
                     }
                     ++idx;
                 }
@@ -238,7 +249,7 @@ TY_HD Fq30 fq30_mulsqr_fused(const Fq30& a, const Fq30& b) {
                     if (wide && k >= 11 && idx >= FIRST) {
                         FQ30_MAC_CC_VV(acc, hi, a.v[i], b.v[k - i]);
                     } else {
-                        acc += (uint64_t)a.v[i] * b.v[k - i];
+                        FQ30_MAD_VV(acc, a.v[i], b.v[k - i]);
                     }
                     ++idx;
                 }
@@ -249,7 +260,7 @@ TY_HD Fq30 fq30_mulsqr_fused(const Fq30& a, const Fq30& b) {
             if (fq30_fused_cap_last(k)) {
                 FQ30_MAC_CC_VS(acc, hi, m[k], fq30_kp(1, 0));
             } else {
-                acc += (uint64_t)m[k] * fq30_kp(1, 0);
+                FQ30_MAD_VS(acc, m[k], fq30_kp(1, 0));
             }
         } else {
             r.v[k - 13] = (uint32_t)acc & FQ30_MASK;

@@ -32,13 +32,16 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_kernel(const uint32
                                                                     const uint32_t* __restrict__ offsets,
                                                                     const uint32_t* __restrict__ sorted,
                                                                     const uint32_t* __restrict__ order,
-                                                                    uint32_t nbuckets, uint32_t cap, uint32_t* buckets) {
+                                                                    uint32_t nbuckets, uint32_t cap, uint32_t init,
+                                                                    uint32_t* buckets) {
     const uint32_t t = blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t >= nbuckets) return;
     const uint32_t g = order[t];
     const uint32_t start = offsets[g];
     const uint32_t end = min(offsets[g + 1], start + cap);  // the tail of a heavy bucket goes to msm_heavy_kernel
-    G1Xyzz acc = G1Xyzz::inf();
+    // init != 0: a later chunk of the same MSM (capi.hip, msm_enqueue) continues from the stored bucket
+    if (init && start >= end) return;
+    G1Xyzz acc = init ? ld_xyzz(buckets, g) : G1Xyzz::inf();
     uint32_t pl_next = 0;
     PackedPoint pk_next;
     if (start < end) {
@@ -86,9 +89,9 @@ __global__ __launch_bounds__(64) void msm_heavy_combine_kernel(const uint32_t* _
 }
 
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
-                      uint32_t nbuckets, uint32_t cap, uint32_t* buckets, hipStream_t s) {
+                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t* buckets, hipStream_t s) {
     hipLaunchKernelGGL(msm_accum_kernel, dim3((nbuckets + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), dim3(MSM_ACC_THREADS), 0,
-                       s, points, offsets, sorted, order, nbuckets, cap, buckets);
+                       s, points, offsets, sorted, order, nbuckets, cap, init ? 1u : 0u, buckets);
 }
 void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist514, const uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s) {
