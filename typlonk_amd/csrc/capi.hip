@@ -114,7 +114,7 @@ struct typlonk_ctx {
     MsmWs ws[MSM_LANES];
     hipStream_t lane[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // lanes 1.. of typlonk_msm_g1_batch* (lane 0 = stream)
     int msm_inflight = 4;           // MSMs of a batch in flight at once (TYPLONK_MSM_INFLIGHT, 1..MSM_LANES)
-    hipEvent_t batch_evt = nullptr;
+    hipEvent_t lane_evt[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // "scalars ready" marks (MsmQueue::submit)
     // NTT
     DevBuf ntt_scratch, ntt_io, quot_ext, ops_tmp, prover_mem;
     bool prover_busy = false;  // one proof in flight per context (the arena above is shared)
@@ -129,6 +129,9 @@ struct typlonk_ctx {
     std::vector<ProfStage> prof;
     std::vector<std::pair<const char*, float>> prof_result;
     int msm_c_override = 0;
+    // TYPLONK_PROVER_OVERLAP (A/B switch): bit 0 = coset transforms of a, b, c, PI in round 1, bit 1 = of Z in round 2,
+    // bit 2 = first opening MSMs of round 3 submitted before the quotient
+    int prover_overlap = 3;   // measured (profiles/r02_ab_prover_overlap.txt): bits 0-1 gain ~1 %, bit 2 loses ~1 %
     int msm_chunks = 0;            // TYPLONK_MSM_CHUNKS: chunks of a stand-alone MSM (0 = choose by length)
     bool ntt_full_tables = true;   // TYPLONK_NTT_FULL_TABLES=0: compose twiddles / coset powers from two-level tables
     uint32_t ntt_full_max_log = 24;
@@ -888,7 +891,59 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     return TYPLONK_OK;
 }
 
-// count independent MSMs over the same SRS, two in flight at a time (alternating workspaces/streams)
+// Asynchronous MSM submissions over one SRS (a prover round, or typlonk_msm_g1_batch_devptr).
+//   submit()    puts an MSM on the next lane of [lane_lo, lanes): the lane first waits for everything queued on the
+//               context's stream so far -- the kernels that produce the scalars -- and a lane that still holds an
+//               unfinished MSM is finished first (the only way submit() blocks).  Work queued on the context's stream
+//               AFTER the call runs concurrently with the MSM.  Lane 0 is the context's stream itself.
+//   wait_all()  finishes every MSM in flight (host-side window combine + affine normalisation of each).
+// out_xy / out_inf of an MSM must stay valid until it has been finished.
+struct MsmQueue {
+    typlonk_ctx* ctx;
+    const SrsEntry* srs;
+    int lanes, lane_lo, next;
+    MsmQueue(typlonk_ctx* c, const SrsEntry* s, int first_lane = 0)
+        : ctx(c), srs(s), lanes(std::max(1, std::min<int>(c->msm_inflight, typlonk_ctx::MSM_LANES))), lane_lo(0), next(0) {
+        set_first_lane(first_lane);
+    }
+    // keep the context's stream (lane 0) free for other work when there is another lane to use
+    void set_first_lane(int l) {
+        lane_lo = (l < lanes) ? l : 0;
+        if (next < lane_lo) next = lane_lo;
+    }
+    int submit(const Fr* d_scalars, size_t m, uint64_t* out_xy, uint8_t* out_inf, bool standalone = false) {
+        size_t off, ml;
+        srs->local_range(m, &off, &ml);
+        if (ml == 0) {
+            write_affine_out(G1Affine::inf(), out_xy, out_inf);
+            return TYPLONK_OK;
+        }
+        if (next >= lanes || next < lane_lo) next = lane_lo;
+        const int l = next++;
+        MsmWs& ws = ctx->ws[l];
+        int rc = msm_finish(ctx, ws);
+        if (rc) return rc;
+        hipStream_t st = ctx->stream;
+        if (l) {
+            if (!ctx->lane[l]) HIPCHK(hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
+            if (!ctx->lane_evt[l]) HIPCHK(hipEventCreateWithFlags(&ctx->lane_evt[l], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ctx->lane_evt[l], ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->lane[l], ctx->lane_evt[l], 0));
+            st = ctx->lane[l];
+        }
+        return msm_enqueue(ctx, ws, st, *srs, d_scalars + off, ml, out_xy, out_inf, standalone);
+    }
+    int wait_all() {
+        int rc = TYPLONK_OK;
+        for (int l = 0; l < typlonk_ctx::MSM_LANES; ++l) {
+            const int r = msm_finish(ctx, ctx->ws[l]);
+            if (!rc) rc = r;
+        }
+        return rc;
+    }
+};
+
+// count independent MSMs over the same SRS, up to MSM_LANES in flight (separate workspaces/streams)
 int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m, size_t count,
               uint64_t* out_xy, uint8_t* out_inf) {
     if (!out_xy || !out_inf || !m || (!d_scalars && count)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
@@ -901,34 +956,12 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
     if (!count) return TYPLONK_OK;
     prof_begin(ctx);
     ProfilingOff prof_off(ctx);  // stage events are per call
-    const int lanes = std::max(1, std::min<int>(ctx->msm_inflight, typlonk_ctx::MSM_LANES));
-    if (!ctx->batch_evt) HIPCHK(hipEventCreateWithFlags(&ctx->batch_evt, hipEventDisableTiming));
-    // work already queued on the context's stream (e.g. the iNTT that produced the scalars) must be
-    // visible to the other lanes
-    HIPCHK(hipEventRecord(ctx->batch_evt, ctx->stream));
-    for (int l = 1; l < lanes; ++l) {
-        if (!ctx->lane[l]) HIPCHK(hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
-        HIPCHK(hipStreamWaitEvent(ctx->lane[l], ctx->batch_evt, 0));
-    }
+    MsmQueue q(ctx, srs);
     int rc = TYPLONK_OK;
-    for (size_t k = 0; k < count && !rc; ++k) {
-        const int l = (int)(k % lanes);
-        MsmWs& ws = ctx->ws[l];
-        if ((rc = msm_finish(ctx, ws))) break;
-        size_t off, ml;
-        srs->local_range(m[k], &off, &ml);
-        if (ml == 0) {
-            write_affine_out(G1Affine::inf(), out_xy + 12 * k, out_inf + k);
-            continue;
-        }
-        rc = msm_enqueue(ctx, ws, l ? ctx->lane[l] : ctx->stream, *srs, (const Fr*)d_scalars[k] + off, ml,
-                         out_xy + 12 * k, out_inf + k, /*standalone=*/count == 1);
-    }
-    for (int l = 0; l < typlonk_ctx::MSM_LANES; ++l) {
-        const int r = msm_finish(ctx, ctx->ws[l]);
-        if (!rc) rc = r;
-    }
-    return rc;
+    for (size_t k = 0; k < count && !rc; ++k)
+        rc = q.submit((const Fr*)d_scalars[k], m[k], out_xy + 12 * k, out_inf + k, /*standalone=*/count == 1);
+    const int r = q.wait_all();
+    return rc ? rc : r;
 }
 
 }  // namespace
@@ -978,6 +1011,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_SORT")) ctx->msm_legacy_sort = (strcmp(e, "atomic") == 0);
     if (const char* e = getenv("TYPLONK_MSM_REDUCE")) ctx->msm_tree_reduce = (strcmp(e, "running") == 0);
     if (const char* e = getenv("TYPLONK_MSM_INFLIGHT")) ctx->msm_inflight = atoi(e);
+    if (const char* e = getenv("TYPLONK_PROVER_OVERLAP")) ctx->prover_overlap = atoi(e);
     if (const char* e = getenv("TYPLONK_MSM_CHUNKS")) ctx->msm_chunks = std::max(0, std::min(atoi(e), MSM_MAX_CHUNKS));
     if (const char* e = getenv("TYPLONK_NTT_FULL_TABLES")) ctx->ntt_full_tables = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_NTT_FULL_MAX_LOG")) ctx->ntt_full_max_log = (uint32_t)atoi(e);
@@ -1012,7 +1046,8 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     }
     for (hipStream_t l : ctx->lane)
         if (l) (void)hipStreamDestroy(l);
-    if (ctx->batch_evt) (void)hipEventDestroy(ctx->batch_evt);
+    for (hipEvent_t e : ctx->lane_evt)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1311,8 +1346,21 @@ int typlonk_circuit_free(typlonk_ctx* ctx, uint32_t circuit_id) {
     return TYPLONK_OK;
 }
 
+namespace {
+// typlonk_quotient_dev with bit k of `extended` set when ext[k] (k = 0..4: a, b, c, Z, PI) already holds that
+// polynomial's coset evaluations -- the prover session extends them in rounds 1 and 2, beside the commitments
+int quotient_run(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out, uint32_t extended);
+}  // namespace
+
 int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out) {
     if (!ctx || !args || !t_out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    // a prover session keeps coset evaluations in the context's quotient workspace between its rounds
+    if (ctx->prover_busy) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "a proof is in flight on this context");
+    return quotient_run(ctx, args, log_n, t_out, 0);
+}
+
+namespace {
+int quotient_run(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out, uint32_t extended) {
     if (log_n < 1 || log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 30");
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n, n4 = 4 * n;
@@ -1345,6 +1393,7 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     const Fr ninv = fe_inv(fr_from_u64(n));
     for (int k = 0; k < (cached ? 5 : 14) && !rc; ++k) {
         if (k == 4 && !has_pi) continue;
+        if (k < 5 && ((extended >> k) & 1u)) continue;
         rc = quotient_extend(ctx, ext + (uint64_t)k * n4, k < 13 ? in[k]->d : nullptr, &ninv, n, log4);
     }
     if (rc) {
@@ -1391,6 +1440,7 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
     rc = ntt_run(ctx, t_out->d, log4, 1, g_limbs, /*sync=*/false);
     return rc;
 }
+}  // namespace
 
 int typlonk_grand_product_dev(typlonk_ctx* ctx, const typlonk_buf* const wires[3], const typlonk_buf* const sigma[3],
                               const uint64_t beta[4], const uint64_t gamma[4], const uint64_t cosets[3][4],
@@ -1506,6 +1556,8 @@ struct typlonk_prover {
     Fr beta, gamma, k[3];
     bool has_pi = true;
     int round = 0;
+    int early = 0;          // opening witnesses of round 3 whose MSM was submitted before the quotient
+    uint32_t extended = 0;  // bit k: coset evaluations of a, b, c, Z, PI already sit in the quotient workspace
     // batched-opening flow (round3_evals / round4_batched)
     bool evals_only = false;
     Fr zeta;
@@ -1516,6 +1568,19 @@ int prover_commit_batch(typlonk_prover* p, const Fr* const* polys, const size_t*
     std::vector<const void*> ptrs(count);
     for (size_t i = 0; i < count; ++i) ptrs[i] = polys[i];
     return msm_batch(p->ctx, p->srs_id, ptrs.data(), m, count, xy, inf);
+}
+// Coset evaluations of one per-proof quotient input (k = 0..4: a, b, c, Z, PI), queued on the context's stream as soon
+// as its coefficients exist.  Rounds 1 and 2 commit on the other lanes at that time, so these transforms fill the
+// latency-bound stretches of the MSMs (sort, bucket reduction) instead of sitting on round 3's critical path.
+int prover_extend(typlonk_prover* p, int k, const Fr* coeffs) {
+    typlonk_ctx* ctx = p->ctx;
+    const uint64_t n4 = 4 * p->n;
+    int rc = ensure(ctx, ctx->quot_ext, (size_t)5 * n4 * sizeof(Fr));
+    if (rc) return rc;
+    const Fr ninv = Fr::one();  // unused: src is never null here
+    rc = quotient_extend(ctx, (Fr*)ctx->quot_ext.p + (uint64_t)k * n4, coeffs, &ninv, p->n, p->log_n + 2);
+    if (!rc) p->extended |= 1u << k;
+    return rc;
 }
 // ops_tmp layout of the prover's openings: [0, 8*2048) per-workgroup carries, then 16 result slots
 constexpr size_t PROVER_EVAL_BLOCKS = 8 * 2048;
@@ -1601,24 +1666,32 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     hipStream_t s = ctx->stream;
     ProfilingOff prof_off(ctx);  // stage events are per call
     // a, b, c = interpolate(columns) (proof.rs:50); the column values themselves are kept for round 2
-    // (proof.rs:113-115 recomputes them with three forward FFTs)
+    // (proof.rs:113-115 recomputes them with three forward FFTs).  Each commitment (round1, proof.rs:107-110) is
+    // submitted to its own lane as soon as its polynomial exists, so the next interpolation and the coset transforms
+    // of the quotient inputs run while it is being sorted and accumulated.
     auto d2d = [&](Fr* dst, const Fr* src) -> int {
         const hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
         return e == hipSuccess ? TYPLONK_OK : fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(e));
     };
+    MsmQueue q(ctx, srs, /*first_lane=*/1);
     for (int i = 0; i < 3 && !rc; ++i) {
         if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
         if ((rc = d2d(p->co[i], wire_evals[i]->d))) break;
-        rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false);
+        if ((rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false))) break;
+        rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
     }
     p->has_pi = pi_evals != nullptr;  // NULL: public inputs [0] -> the zero polynomial
     if (!rc && p->has_pi) {
         rc = d2d(p->pi, pi_evals->d);
         if (!rc) rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
     }
-    if (!rc) {
-        const size_t m[3] = {n, n, n};
-        rc = prover_commit_batch(p, p->co, m, 3, &commit_xy[0][0], commit_inf);  // round1, proof.rs:107-110
+    if (ctx->prover_overlap & 1) {
+        for (int i = 0; i < 3 && !rc; ++i) rc = prover_extend(p, i, p->co[i]);
+        if (!rc && p->has_pi) rc = prover_extend(p, 4, p->pi);
+    }
+    {
+        const int r = q.wait_all();
+        if (!rc) rc = r;
     }
     if (rc) {
         delete p;
@@ -1652,9 +1725,15 @@ int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint6
     int rc = typlonk_grand_product_dev(ctx, wp, sp, beta, gamma, cosets, p->log_n, &zb);  // proof.rs:119-120
     if (!rc) rc = ntt_run(ctx, p->z, p->log_n, 1, nullptr, false);                          // :127-128
     if (!rc) {
-        const Fr* polys[1] = {p->z};
-        const size_t m[1] = {n};
-        rc = prover_commit_batch(p, polys, m, 1, z_xy, z_inf);                              // :129
+        const SrsEntry* srs = nullptr;
+        rc = msm_validate(ctx, p->srs_id, n, &srs);
+        if (!rc) {
+            MsmQueue q(ctx, srs, /*first_lane=*/1);
+            rc = q.submit(p->z, n, z_xy, z_inf, /*standalone=*/true);                       // :129
+            if (!rc && (ctx->prover_overlap & 2)) rc = prover_extend(p, 3, p->z);  // Z's coset transform runs beside its commitment
+            const int r = q.wait_all();
+            if (!rc) rc = r;
+        }
     }
     if (!rc) p->round = 2;
     return rc;
@@ -1679,22 +1758,18 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
     memcpy(al.v, alpha, 32);
     memcpy(ze.v, zeta, 32);
     ProfilingOff prof_off(ctx);  // stage events are per call
-    int rc;
-    // ---- quotient (proof.rs:139-145) ----
-    {
-        typlonk_buf b[5] = {{p->co[0], n}, {p->co[1], n}, {p->co[2], n}, {p->z, n}, {p->pi, n}};
-        typlonk_buf tb{p->t, 4 * n};
-        typlonk_quotient_args qa{};
-        for (int i = 0; i < 3; ++i) qa.wires[i] = &b[i];
-        qa.z = &b[3];
-        qa.public_inputs = p->has_pi ? &b[4] : nullptr;
-        memcpy(qa.alpha, alpha, 32);
-        memcpy(qa.beta, p->beta.v, 32);
-        memcpy(qa.gamma, p->gamma.v, 32);
-        for (int i = 0; i < 3; ++i) memcpy(qa.cosets[i], p->k[i].v, 32);
-        qa.circuit = p->circuit;
-        rc = typlonk_quotient_dev(ctx, &qa, log_n, &tb);
-    }
+    const SrsEntry* srs = nullptr;
+    int rc = msm_validate(ctx, p->srs_id, n, &srs);
+    if (rc) return rc;
+    // commitments of this round: 6 opening witnesses + 3 quotient slices (:181).  The queue outlives every early
+    // return (its destructor-side wait below), because the MSMs write into xy / inf.
+    uint64_t xy[9][12];
+    uint8_t inf[9];
+    MsmQueue q(ctx, srs, /*first_lane=*/1);
+    struct WaitAll {
+        MsmQueue& q;
+        ~WaitAll() { (void)q.wait_all(); }
+    } wait_guard{q};
     // ---- openings of a, b, c at zeta; Z at zeta and zeta*w (proof.rs:147-163) ----
     Fr ev[6];
     const Fr w = fr_domain_root(log_n);
@@ -1720,6 +1795,28 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
         if (p->has_pi) at_zeta[cnt++] = p->pi;
         if (!rc) rc = prover_eval_async(p, at_zeta, cnt, n, ze, first);
         if (!rc) rc = prover_open_async(p, p->z, n, zw, p->q[4], 8);
+        // the witnesses of a, b, c at zeta need nothing else: their MSMs start on the lanes beside the context's
+        // stream while the quotient below (and the linearisation after it) is still being computed
+        int early = 0;
+        if (!batched && (ctx->prover_overlap & 4))
+            for (; early < 3 && early < q.lanes - 1 && !rc; ++early) rc = q.submit(p->q[early], n - 1, xy[early], inf + early);
+        p->early = early;
+        // ---- quotient (proof.rs:139-145): queued behind the opening scans; a, b, c, Z (and PI) were transformed to the
+        // coset domain in rounds 1 and 2, so what is left is the pointwise kernel and one inverse transform ----
+        if (!rc) {
+            typlonk_buf b[5] = {{p->co[0], n}, {p->co[1], n}, {p->co[2], n}, {p->z, n}, {p->pi, n}};
+            typlonk_buf tb{p->t, 4 * n};
+            typlonk_quotient_args qa{};
+            for (int i = 0; i < 3; ++i) qa.wires[i] = &b[i];
+            qa.z = &b[3];
+            qa.public_inputs = p->has_pi ? &b[4] : nullptr;
+            memcpy(qa.alpha, alpha, 32);
+            memcpy(qa.beta, p->beta.v, 32);
+            memcpy(qa.gamma, p->gamma.v, 32);
+            for (int i = 0; i < 3; ++i) memcpy(qa.cosets[i], p->k[i].v, 32);
+            qa.circuit = p->circuit;
+            rc = quotient_run(ctx, &qa, log_n, &tb, p->extended);
+        }
         if (!rc) rc = prover_fetch(p, host, 9);
         for (int i = 0; i < 4; ++i) ev[i] = host[i];
         ev[4] = host[8];
@@ -1777,9 +1874,12 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
     if (!rc && !batched) {
         const Fr* polys[9] = {p->q[0], p->q[1], p->q[2], p->q[3], p->q[4], p->q[5], p->t, p->t + n, p->t + 2 * n};
         const size_t m[9] = {n - 1, n - 1, n - 1, n - 1, n - 1, n - 1, n, n, n > 3 ? n - 3 : 0};
-        uint64_t xy[9][12];
-        uint8_t inf[9];
-        rc = prover_commit_batch(p, polys, m, 9, &xy[0][0], inf);
+        q.set_first_lane(0);  // the context's stream has nothing left to do but commit
+        for (int k = p->early; k < 9 && !rc; ++k) rc = q.submit(polys[k], m[k], xy[k], inf + k);
+        {
+            const int r = q.wait_all();
+            if (!rc) rc = r;
+        }
         if (!rc) {
             memcpy(out->w_xy, xy, 6 * 96);
             memcpy(out->w_inf, inf, 6);

@@ -111,10 +111,108 @@ struct Fe {
     TY_HD bool operator!=(const Fe& b) const { return !(*this == b); }
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- 8-limb (Fr) carry chains in inline assembly -------------------------------------------------------------------
+// The portable forms below (64-bit temporaries) compile to a v_mov + v_lshl_add_u64 pair per limb on gfx950: an
+// addition + conditional subtraction costs ~60 instructions, and the three of a radix-2 butterfly (add, sub, the
+// multiplication's final reduction) were ~30 % of its time.  Written as v_add_co / v_addc_co chains they are 24-25
+// instructions each.  (N = 12 keeps the portable form: Fq only runs at set-up time.)
+#define TY_L8(x) "v"((x)[0]), "v"((x)[1]), "v"((x)[2]), "v"((x)[3]), "v"((x)[4]), "v"((x)[5]), "v"((x)[6]), "v"((x)[7])
+#define TY_O8(x) "=&v"((x)[0]), "=&v"((x)[1]), "=&v"((x)[2]), "=&v"((x)[3]), "=&v"((x)[4]), "=&v"((x)[5]), "=&v"((x)[6]), "=&v"((x)[7])
+// modulus limbs: in VGPRs for the carry chains (VOP2 with a carry-in already reads VCC, and gfx9 allows ONE constant-bus
+// operand per instruction), in SGPRs where no carry is involved
+#define TY_M8V(P) "v"(P::mod(0)), "v"(P::mod(1)), "v"(P::mod(2)), "v"(P::mod(3)), "v"(P::mod(4)), "v"(P::mod(5)), "v"(P::mod(6)), "v"(P::mod(7))
+#define TY_M8(P) "s"(P::mod(0)), "s"(P::mod(1)), "s"(P::mod(2)), "s"(P::mod(3)), "s"(P::mod(4)), "s"(P::mod(5)), "s"(P::mod(6)), "s"(P::mod(7))
+// r = a + b   (no carry out of limb 7: both operands < 2^255)
+__device__ __forceinline__ void ty_add8(uint32_t (&r)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    asm("v_add_co_u32 %0, vcc, %8, %16\n\t"
+        "v_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %15, %23, vcc"
+        : TY_O8(r)
+        : TY_L8(a), TY_L8(b)
+        : "vcc");
+}
+// d = x - p if x >= p else x   (x < 2p)
+template <class P>
+__device__ __forceinline__ void ty_csub8(uint32_t (&d)[8], const uint32_t (&x)[8]) {
+    asm("v_subrev_co_u32 %0, vcc, %16, %8\n\t"
+        "v_subbrev_co_u32 %1, vcc, %17, %9, vcc\n\t"
+        "v_subbrev_co_u32 %2, vcc, %18, %10, vcc\n\t"
+        "v_subbrev_co_u32 %3, vcc, %19, %11, vcc\n\t"
+        "v_subbrev_co_u32 %4, vcc, %20, %12, vcc\n\t"
+        "v_subbrev_co_u32 %5, vcc, %21, %13, vcc\n\t"
+        "v_subbrev_co_u32 %6, vcc, %22, %14, vcc\n\t"
+        "v_subbrev_co_u32 %7, vcc, %23, %15, vcc\n\t"
+        "v_cndmask_b32 %0, %0, %8, vcc\n\t"   // borrow: x < p, keep x
+        "v_cndmask_b32 %1, %1, %9, vcc\n\t"
+        "v_cndmask_b32 %2, %2, %10, vcc\n\t"
+        "v_cndmask_b32 %3, %3, %11, vcc\n\t"
+        "v_cndmask_b32 %4, %4, %12, vcc\n\t"
+        "v_cndmask_b32 %5, %5, %13, vcc\n\t"
+        "v_cndmask_b32 %6, %6, %14, vcc\n\t"
+        "v_cndmask_b32 %7, %7, %15, vcc"
+        : TY_O8(d)
+        : TY_L8(x), TY_M8V(P)
+        : "vcc");
+}
+// r = a - b mod 2^256, m = all ones if the subtraction wrapped else 0
+__device__ __forceinline__ void ty_sub8(uint32_t (&r)[8], uint32_t& m, const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_cndmask_b32 %8, 0, -1, vcc"
+        : TY_O8(r), "=&v"(m)
+        : TY_L8(a), TY_L8(b)
+        : "vcc");
+}
+// o = r + (p & m)
+template <class P>
+__device__ __forceinline__ void ty_addmask8(uint32_t (&o)[8], const uint32_t (&r)[8], uint32_t m) {
+    asm("v_and_b32 %0, %17, %16\n\t"
+        "v_and_b32 %1, %18, %16\n\t"
+        "v_and_b32 %2, %19, %16\n\t"
+        "v_and_b32 %3, %20, %16\n\t"
+        "v_and_b32 %4, %21, %16\n\t"
+        "v_and_b32 %5, %22, %16\n\t"
+        "v_and_b32 %6, %23, %16\n\t"
+        "v_and_b32 %7, %24, %16\n\t"
+        "v_add_co_u32 %0, vcc, %8, %0\n\t"
+        "v_addc_co_u32 %1, vcc, %9, %1, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %10, %2, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %11, %3, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %12, %4, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %13, %5, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %14, %6, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %15, %7, vcc"
+        : TY_O8(o)
+        : TY_L8(r), "v"(m), TY_M8(P)
+        : "vcc");
+}
+#endif
+
 // r = a - p if a >= p else a          (a < 2p)
 template <class P>
 TY_HD void fe_reduce_once(Fe<P>& a) {
     constexpr int N = P::N;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (N == 8) {
+        uint32_t d[8];
+        ty_csub8<P>(d, a.v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.v[i] = d[i];
+        return;
+    }
+#endif
     uint32_t d[N];
     uint64_t borrow = 0;
 #pragma unroll
@@ -133,6 +231,14 @@ template <class P>
 TY_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
     constexpr int N = P::N;
     Fe<P> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (N == 8) {
+        uint32_t t[8];
+        ty_add8(t, a.v, b.v);
+        ty_csub8<P>(r.v, t);
+        return r;
+    }
+#endif
     uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -148,6 +254,14 @@ template <class P>
 TY_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     constexpr int N = P::N;
     Fe<P> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (N == 8) {
+        uint32_t t[8], m;
+        ty_sub8(t, m, a.v, b.v);
+        ty_addmask8<P>(r.v, t, m);
+        return r;
+    }
+#endif
     uint64_t borrow = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
