@@ -67,7 +67,10 @@ def pmc_traffic(kernel: str):
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
-            return float(json.load(f)[kernel]["traffic_bytes_per_launch"])
+            d = json.load(f)
+        # a stand-alone 2^20 MSM launches the accumulation once per chunk of terms (two chunks): per-MSM traffic
+        per_msm = d.get("_meta", {}).get("accum_launches_per_msm", 1) if kernel == "ty::msm_accum_kernel" else 1
+        return float(d[kernel]["traffic_bytes_per_launch"]) * per_msm
     except Exception:
         return None
 
@@ -182,7 +185,7 @@ def main() -> None:
         result["roofline"] = {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                               "traffic": pmc_traffic("ty::msm_accum_kernel") if world == 1 and log_n == 20 else None,
-                              "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, bytes per launch)",
+                              "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, bytes per MSM = both accumulation launches)",
                               "algorithmic_bytes": alg_bytes,
                               "kernel_ms": t_acc * 1e3, "mixed_adds_per_s": W * m_local / t_acc,
                               "limited_by": "valu",

@@ -41,6 +41,14 @@ void shim_fq_sub2(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint3
 void shim_fq_mul3(const uint32_t* a, uint32_t* o) { stq(o, fq30_mulk_lazy<3>(lift(ldq(a), 1))); }
 void shim_fq_neg(const uint32_t* a, uint32_t* o) { stq(o, fq30_neg_lazy<1>(ldq(a))); }
 void shim_fq_inv(const uint32_t* a, uint32_t* o) { stq(o, fq30_inv(ldq(a))); }
+// host inversion (binary Euclid) against the Fermat ladder the device uses, la extra multiples of p on the input
+int shim_fq_inv_agree(const uint32_t* a, int la) {
+    const Fq30 x = lift(ldq(a), la);
+    const Fq30 g = fq30_canon(fq30_inv(x)), f = fq30_canon(fq30_inv_fermat(fq30_canon(x)));
+    for (int i = 0; i < 13; ++i)
+        if (g.v[i] != f.v[i]) return 0;
+    return 1;
+}
 int shim_fq_is_zero_mod(const uint32_t* a, int la) { return fq30_is_zero_mod(lift(ldq(a), la)) ? 1 : 0; }
 // pack(unpack(w)) on raw words (any 384-bit pattern whose value is < 2^384)
 void shim_fq_pack_unpack(const uint32_t* w, uint32_t* o) { uint32_t t[12]; memcpy(t, w, 48); uint32_t r[12]; fq30_pack(fq30_unpack(t), r); memcpy(o, r, 48); }

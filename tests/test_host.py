@@ -74,8 +74,11 @@ def test_fq30_arithmetic_vs_bigint(shim):
         assert shim.shim_fq_is_zero_mod(u32p(_fq(a)), 0) == (1 if a == 0 else 0)
     assert shim.shim_fq_is_zero_mod(u32p(_fq(0)), 1) == 1       # the value p itself
     assert shim.shim_fq_is_zero_mod(u32p(_fq(1)), 1) == 0
-    for a in [1, 2, 5, O.P - 1, rnd.randrange(O.P)]:
+    for a in [1, 2, 5, O.P - 1, (O.P + 1) // 2, 1 << 380] + [rnd.randrange(O.P) for _ in range(40)]:
         assert _q(shim, "shim_fq_inv", _fq(a)) == pow(a, -1, O.P)
+        for la in (0, 1, 5):   # lazily reduced inputs; the host's Euclid inversion equals the device's Fermat ladder
+            assert shim.shim_fq_inv_agree(u32p(_fq(a)), la) == 1
+    assert _q(shim, "shim_fq_inv", _fq(0)) == 0
     # pack/unpack is the identity on any 384-bit word pattern
     for _ in range(50):
         w = np.array([rnd.getrandbits(64) for _ in range(6)], dtype=np.uint64)

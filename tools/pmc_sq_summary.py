@@ -15,9 +15,11 @@ import sys
 
 def main():
     d = sys.argv[1].rstrip("/") + "/"
-    cc = glob.glob(d + "*counter_collection.csv")[0]
-    kt = glob.glob(d + "*kernel_trace.csv")[0]
-    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))}
+    cc = glob.glob(d + "**/*counter_collection.csv", recursive=True)[0]
+    kts = glob.glob(d + "**/*kernel_trace.csv", recursive=True)
+    # durations: the kernel trace when the pass has one, else the timestamps rocprofv3 >= 1.0 puts on every counter row
+    src = kts[0] if kts else cc
+    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(src))}
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(cc)):
         name = r["Kernel_Name"].split("(")[0]

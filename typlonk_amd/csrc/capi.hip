@@ -127,6 +127,7 @@ struct typlonk_ctx {
     // profiling
     bool profiling = false;
     std::vector<ProfStage> prof;
+    std::vector<hipEvent_t> event_pool;  // timing events of finished stages, reused by the next call
     std::vector<std::pair<const char*, float>> prof_result;
     int msm_c_override = 0;
     // TYPLONK_PROVER_OVERLAP (A/B switch): bit 0 = coset transforms of a, b, c, PI in round 1, bit 1 = of Z in round 2,
@@ -202,10 +203,21 @@ struct StageTimer {
     hipStream_t st;
     StageTimer(typlonk_ctx* c, const char* n, hipStream_t s = nullptr) : ctx(c), on(c->profiling), name(n), st(s ? s : c->stream) {
         if (on) {
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
+            a = take();
+            b = take();
             (void)hipEventRecord(a, st);
         }
+    }
+    // events are recycled through the context (creating two per stage and call costs more than recording them)
+    hipEvent_t take() {
+        hipEvent_t e = nullptr;
+        if (!ctx->event_pool.empty()) {
+            e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            (void)hipEventCreate(&e);
+        }
+        return e;
     }
     ~StageTimer() {
         if (on) {
@@ -217,8 +229,8 @@ struct StageTimer {
 
 void prof_begin(typlonk_ctx* ctx) {
     for (auto& s : ctx->prof) {
-        (void)hipEventDestroy(s.a);
-        (void)hipEventDestroy(s.b);
+        ctx->event_pool.push_back(s.a);
+        ctx->event_pool.push_back(s.b);
     }
     ctx->prof.clear();
 }
@@ -1024,6 +1036,8 @@ void typlonk_destroy(typlonk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     prof_begin(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    ctx->event_pool.clear();
     for (auto& kv : ctx->srs) (void)hipFree(kv.second.d_points);
     for (auto& kv : ctx->circuits) {
         (void)hipFree(kv.second.ext);

@@ -448,8 +448,112 @@ TY_HD void fq30_to_ark(const Fq30& a, uint32_t (&w)[12]) {
     fq30_pack(fq30_canon(fq30_mul(a, c)), w);
 }
 
-// a^-1 (Fermat, a^(p-2)); input < 2p, output < 1.01 p.  0 -> 0.
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host-side inversion by the binary extended Euclid algorithm on six 64-bit words: ~10 us instead of the ~50 us of the
+// Fermat ladder below.  It is the last step of every MSM (canonical affine output, g1_to_affine), on the host's critical
+// path.  Data-dependent branches are no concern here: the inverted value is a projective denominator of a public result.
+struct Fq30U384 {
+    uint64_t w[6];
+};
+inline bool fq30_u384_geq(const Fq30U384& a, const Fq30U384& b) {
+    for (int i = 5; i >= 0; --i)
+        if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+    return true;
+}
+inline void fq30_u384_sub(Fq30U384& a, const Fq30U384& b) {  // a -= b (a >= b)
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 6; ++i) {
+        const unsigned __int128 t = (unsigned __int128)a.w[i] - b.w[i] - (uint64_t)br;
+        a.w[i] = (uint64_t)t;
+        br = (t >> 64) & 1;
+    }
+}
+inline uint64_t fq30_u384_add(Fq30U384& a, const Fq30U384& b) {  // a += b, returns the carry out
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 6; ++i) {
+        c += (unsigned __int128)a.w[i] + b.w[i];
+        a.w[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    return (uint64_t)c;
+}
+inline void fq30_u384_shr1(Fq30U384& a, uint64_t top) {
+    for (int i = 0; i < 5; ++i) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 63);
+    a.w[5] = (a.w[5] >> 1) | (top << 63);
+}
+inline bool fq30_u384_is_one(const Fq30U384& a) { return a.w[0] == 1 && !(a.w[1] | a.w[2] | a.w[3] | a.w[4] | a.w[5]); }
+// x / 2 mod p for x < p
+inline void fq30_u384_half_mod(Fq30U384& x, const Fq30U384& p) {
+    if (x.w[0] & 1) {
+        const uint64_t c = fq30_u384_add(x, p);  // x + p is even and < 2^382: no carry, but keep the general form
+        fq30_u384_shr1(x, c);
+    } else {
+        fq30_u384_shr1(x, 0);
+    }
+}
+inline Fq30 fq30_inv_gcd(const Fq30& a) {
+    static const Fq30U384 P = {{0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull,
+                                0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull}};
+    const Fq30 c = fq30_canon(a);
+    if (fq30_is_zero_exact(c)) return fq30_zero();
+    // the residue itself, as a plain integer < p
+    Fq30U384 u = {{0, 0, 0, 0, 0, 0}}, v = P, x1 = {{1, 0, 0, 0, 0, 0}}, x2 = {{0, 0, 0, 0, 0, 0}};
+    for (int i = 0; i < 13; ++i) {
+        const int bit = 30 * i, wi = bit >> 6, sh = bit & 63;
+        u.w[wi] |= (uint64_t)c.v[i] << sh;
+        if (sh > 34 && wi + 1 < 6) u.w[wi + 1] |= (uint64_t)c.v[i] >> (64 - sh);
+    }
+    // invariant: x1 * residue = u, x2 * residue = v (mod p)
+    while (!fq30_u384_is_one(u) && !fq30_u384_is_one(v)) {
+        while (!(u.w[0] & 1)) {
+            fq30_u384_shr1(u, 0);
+            fq30_u384_half_mod(x1, P);
+        }
+        while (!(v.w[0] & 1)) {
+            fq30_u384_shr1(v, 0);
+            fq30_u384_half_mod(x2, P);
+        }
+        if (fq30_u384_geq(u, v)) {
+            fq30_u384_sub(u, v);
+            if (!fq30_u384_geq(x1, x2)) fq30_u384_add(x1, P);
+            fq30_u384_sub(x1, x2);
+        } else {
+            fq30_u384_sub(v, u);
+            if (!fq30_u384_geq(x2, x1)) fq30_u384_add(x2, P);
+            fq30_u384_sub(x2, x1);
+        }
+    }
+    const Fq30U384& inv = fq30_u384_is_one(u) ? x1 : x2;  // residue^-1 as a plain integer < p
+    Fq30 r;
+    for (int i = 0; i < 13; ++i) {
+        const int bit = 30 * i, wi = bit >> 6, sh = bit & 63;
+        uint64_t x = inv.w[wi] >> sh;
+        if (sh > 34 && wi + 1 < 6) x |= inv.w[wi + 1] << (64 - sh);
+        r.v[i] = (uint32_t)x & FQ30_MASK;
+    }
+    // (a R)^-1 -> a^-1 R: times R^2, i.e. one Montgomery product with R^3 mod p
+    constexpr uint32_t R3[13] = {0x1347c98du, 0x2c2194ccu, 0x1b027ceau, 0x2b8cb5a5u, 0x1214bbdeu, 0x0b5efd04u, 0x39edd0bfu,
+                                 0x1b2b39a4u, 0x32b00b66u, 0x1d1b6db4u, 0x3b8f0b8fu, 0x12c853b7u, 0x0006d0afu};
+    Fq30 k;
+    for (int i = 0; i < 13; ++i) k.v[i] = R3[i];
+    return fq30_mul(r, k);
+}
+#endif
+
+// Fermat ladder a^(p-2): the device form (srs_gen.hip), and the reference the host's Euclid inversion is tested against
+TY_HD Fq30 fq30_inv_fermat(const Fq30& a);
+
+// a^-1; input < 8p, output < 1.01 p.  0 -> 0.
 TY_HD Fq30 fq30_inv(const Fq30& a) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return fq30_inv_gcd(a);
+#else
+    return fq30_inv_fermat(a);
+#endif
+}
+
+// a^-1 (Fermat, a^(p-2)); input < 2p, output < 1.01 p.  0 -> 0.
+TY_HD Fq30 fq30_inv_fermat(const Fq30& a) {
     // exponent p - 2 as 32-bit words (little endian)
     constexpr uint32_t e[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                                 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
