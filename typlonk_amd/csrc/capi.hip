@@ -664,9 +664,10 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     uint32_t nch = 1;
     if (standalone && !ctx->msm_legacy_sort) {
         // measured (tools/msm_chunks.py, profiles/r02_msm_chunks.jsonl): the overlapped sort is not free -- it competes
-        // with the accumulation for issue slots -- so two chunks are the best split at 2^20 terms (2.78 -> 2.73 ms) and
-        // below 2^20 one chunk wins
-        nch = ctx->msm_chunks ? (uint32_t)ctx->msm_chunks : (m >= (1u << 20) ? 2u : 1u);
+        // with the accumulation for issue slots -- and chunks of ~2^19 terms are the best grain: 2 chunks at 2^20
+        // (2.76 -> 2.68 ms), 4 at 2^21 (5.09 -> 4.81), 8 at 2^22 (9.92 -> 8.99); below 2^20 one chunk wins
+        nch = ctx->msm_chunks ? (uint32_t)ctx->msm_chunks
+                              : (m >= (1u << 20) ? (uint32_t)std::min<size_t>(m >> 19, MSM_MAX_CHUNKS) : 1u);
         while (nch > 1 && m / nch < 4096) --nch;
     }
     const size_t step = (m + nch - 1) / nch;
