@@ -1,5 +1,7 @@
 // MSM staging kernels: infinity marking, scalar -> signed window digits + histogram, exclusive scan,
 // counting-sort scatter.  See msm_common.hpp for the overall MSM structure.
+#include <stdlib.h>
+
 #include "launch.hpp"
 #include "msm_common.hpp"
 
@@ -159,8 +161,27 @@ __global__ __launch_bounds__(256) void scan_finish_kernel(const uint32_t* in, ui
 // Level-1 entry: idx (23 bits) | sign << 23 | (b & (2^lb - 1)) << 24     (m <= 2^23)
 // scalars per workgroup: 2048 (8 per thread) up to 2^20 terms, growing with m beyond that so the
 // workgroup x segment matrix (nblk * nseg counters) stays bounded instead of growing like m^2
-__host__ __device__ inline uint32_t msm_chunk_for(uint64_t m) {
-    uint32_t chunk = 2048;
+// threads per workgroup of the level-1 passes (TYPLONK_SEG1_THREADS = 256 | 512 | 1024 for measurements): a bigger
+// workgroup owns a longer chunk, so its run inside each segment is longer and the scattered 4-byte stores of
+// msm_seg_scatter_kernel fill more of every 128-byte line
+inline uint32_t msm_seg1_threads() {
+    static const uint32_t t = [] {
+        const char* e = getenv("TYPLONK_SEG1_THREADS");
+        const int v = e ? atoi(e) : 256;
+        return (uint32_t)((v == 512 || v == 1024) ? v : 256);
+    }();
+    return t;
+}
+inline uint32_t msm_seg1_per_thread() {
+    static const uint32_t t = [] {
+        const char* e = getenv("TYPLONK_SEG1_PER_THREAD");
+        const int v = e ? atoi(e) : 8;
+        return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 16 || v == 32) ? v : 8);
+    }();
+    return t;
+}
+inline uint32_t msm_chunk_for(uint64_t m) {
+    uint32_t chunk = msm_seg1_per_thread() * msm_seg1_threads();
     while (((uint64_t)chunk << 9) < m) chunk <<= 1;  // at most 512 workgroups
     return chunk;
 }
@@ -212,14 +233,15 @@ __device__ __forceinline__ void msm_load_canon(const Fr* scalars, uint64_t i, ui
     for (int k = 0; k < 8; ++k) out[k] = s.v[k];
 }
 
-__global__ __launch_bounds__(256) void msm_seg_hist_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
-                                                           uint32_t* blk_hist) {
+__global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
+                                                            uint32_t* blk_hist) {
     extern __shared__ uint32_t seg_h[];
-    for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) seg_h[s] = 0;
+    const uint32_t nt = blockDim.x;
+    for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) seg_h[s] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
-    for (uint32_t e = 0; e < sh.chunk / 256; ++e) {
-        const uint64_t i = base + threadIdx.x + 256 * e;
+    for (uint32_t e = 0; e < sh.chunk / nt; ++e) {
+        const uint64_t i = base + threadIdx.x + nt * e;
         if (i < m) {
             uint32_t v[8];
             msm_load_canon(scalars, i, v);
@@ -229,19 +251,20 @@ __global__ __launch_bounds__(256) void msm_seg_hist_kernel(const Fr* scalars, ui
         }
     }
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) blk_hist[(uint64_t)s * sh.nblk + blockIdx.x] = seg_h[s];
+    for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) blk_hist[(uint64_t)s * sh.nblk + blockIdx.x] = seg_h[s];
 }
 
-__global__ __launch_bounds__(256) void msm_seg_scatter_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
-                                                              const uint32_t* blk_base, uint32_t* entries) {
+__global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
+                                                               const uint32_t* blk_base, uint32_t* entries) {
     extern __shared__ uint32_t seg_sm[];
     uint32_t* cur = seg_sm;             // running position of this workgroup inside each segment
-    for (uint32_t s = threadIdx.x; s < sh.nseg; s += 256) cur[s] = blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
+    const uint32_t nt = blockDim.x;
+    for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] = blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
     const uint32_t lmask = (1u << sh.lb) - 1;
-    for (uint32_t e = 0; e < sh.chunk / 256; ++e) {
-        const uint64_t i = base + threadIdx.x + 256 * e;
+    for (uint32_t e = 0; e < sh.chunk / nt; ++e) {
+        const uint64_t i = base + threadIdx.x + nt * e;
         if (i < m) {
             uint32_t v[8];
             msm_load_canon(scalars, i, v);
@@ -429,10 +452,11 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
     sh.chunk = msm_chunk_for(m);
     sh.nblk = (uint32_t)((m + sh.chunk - 1) / sh.chunk);
     const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
-    hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(256), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
+    const uint32_t nt1 = msm_seg1_threads();
+    hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
                        blk_hist);
     launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, s);
-    hipLaunchKernelGGL(msm_seg_scatter_kernel, dim3(sh.nblk), dim3(256), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
+    hipLaunchKernelGGL(msm_seg_scatter_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
                        blk_base, entries);
     hipLaunchKernelGGL(msm_seg_sort_kernel, dim3(sh.nseg), dim3(256), 0, s, entries, blk_base, sh, (uint32_t)nmat, counts,
                        offsets, sorted);
