@@ -38,8 +38,8 @@ from typlonk_amd.dist import ShardedMsm, local_range  # noqa: E402
 FR_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # what actually bounds the accumulation: the vector-ALU rate of the XYZZ mixed addition, measured by the
-# self-checking micro-benchmark tools/ubench2 (profiles/r02_ubench2_fused_y3.txt: 2 waves/SIMD, 128-thread blocks)
-MIXED_ADD_CEILING = 6.97e9
+# self-checking micro-benchmark tools/ubench2 (profiles/r02_ubench2_fused_y3.txt: best of the 2-waves-per-SIMD runs)
+MIXED_ADD_CEILING = 7.13e9
 
 
 def fr_mont_limbs(x: int) -> np.ndarray:
@@ -68,9 +68,7 @@ def pmc_traffic(kernel: str):
     try:
         with open(path) as f:
             d = json.load(f)
-        # a stand-alone 2^20 MSM launches the accumulation once per chunk of terms (two chunks): per-MSM traffic
-        per_msm = d.get("_meta", {}).get("accum_launches_per_msm", 1) if kernel == "ty::msm_accum_kernel" else 1
-        return float(d[kernel]["traffic_bytes_per_launch"]) * per_msm
+        return float(d[kernel]["traffic_bytes_per_launch"])
     except Exception:
         return None
 
@@ -88,6 +86,9 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=1 << 16,
                     help="terms of the workload timed on the CPU oracle (2^16 ~ 16 s on one host core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-only", action="store_true",
+                    help="only the timed MSM loop and its roofline (the command the rocprofv3 summaries "
+                         "profiles/r02_kernel_stats_bench_msm_only.csv are taken from)")
     ap.add_argument("--no-sharded-prove", action="store_true",
                     help="N > 1: skip the extra measurement of prove() with every MSM sharded over the ranks")
     ap.add_argument("--tables", type=int, default=20,
@@ -148,13 +149,14 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
-    accum_ms, stage_ms = [], {}
+    stage_ms, accum_launches = {}, 0
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_xy, out_inf = step()
         for name, ms in ctx.profile():
             stage_ms[name] = stage_ms.get(name, 0.0) + ms
+            accum_launches += name == "msm_accum"
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -178,24 +180,30 @@ def main() -> None:
     }
 
     # ---- roofline of the dominant kernel (bucket accumulation), HIP events on the launch stream ----
-    t_acc = stage_ms.get("msm_accum", 0.0) * 1e-3
-    alg_bytes = 128.0 * m_local  # 32 B scalar + 96 B affine base per term, each read once
+    # A stand-alone MSM of >= 2^20 terms launches the accumulation once per chunk of ~2^19 terms (capi.hip, msm_enqueue):
+    # everything below is PER LAUNCH, as rocprofv3's per-kernel average is (profiles/r02_kernel_stats_bench_msm_only.csv).
+    launches = max(1, accum_launches // max(1, args.steps))
+    t_acc = stage_ms.get("msm_accum", 0.0) * 1e-3 / launches
+    terms_per_launch = m_local / launches
+    alg_bytes = 128.0 * terms_per_launch  # 32 B scalar + 96 B affine base per term, each read once
     if t_acc > 0:
         ach = alg_bytes / t_acc / 1e9
+        adds = W * terms_per_launch / t_acc
         result["roofline"] = {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                               "traffic": pmc_traffic("ty::msm_accum_kernel") if world == 1 and log_n == 20 else None,
-                              "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, bytes per MSM = both accumulation launches)",
-                              "algorithmic_bytes": alg_bytes,
-                              "kernel_ms": t_acc * 1e3, "mixed_adds_per_s": W * m_local / t_acc,
+                              "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE "
+                                                "passes, bytes per launch)",
+                              "algorithmic_bytes": alg_bytes, "launches_per_msm": launches,
+                              "terms_per_launch": terms_per_launch, "kernel_ms": t_acc * 1e3, "mixed_adds_per_s": adds,
                               "limited_by": "valu",
-                              "valu": {"achieved": W * m_local / t_acc, "peak": MIXED_ADD_CEILING, "unit": "mixed adds/s",
-                                       "frac": W * m_local / t_acc / MIXED_ADD_CEILING,
+                              "valu": {"achieved": adds, "peak": MIXED_ADD_CEILING, "unit": "mixed adds/s",
+                                       "frac": adds / MIXED_ADD_CEILING,
                                        "peak_source": "tools/ubench2 (profiles/r02_ubench2_fused_y3.txt)"},
                               "note": "the HBM fraction is what the contract asks for; the kernel is integer-VALU-bound "
-                                      "(92 % of the issue slots, profiles/r01_pmc_sq_valu_msm.json) -- see DESIGN.md"}
+                                      "(91 % of the issue slots at 2.06 GHz, profiles/r02_pmc_sq_valu_msm.json) -- see DESIGN.md"}
 
-    if rank == 0:
+    if rank == 0 and not args.msm_only:
         # ---- NTT 2^log_n, resident data -----------------------------------------------------------
         v = synthetic_scalars(n, 0xA11CE, device)
         for _ in range(2):
@@ -212,7 +220,7 @@ def main() -> None:
                          "algorithmic_GBps": 64.0 * n / (kern / reps * 1e-3) / 1e9,
                          "frac_of_hbm_peak": 64.0 * n / (kern / reps * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.msm_only:
         # ---- kernel sequence of one prove(): 15 size-n NTTs, the quotient on the
         # 4n coset domain (per-circuit constants cached by typlonk_circuit_load), 13 MSMs in the groups
         # prove() issues them.  Timing only: the polynomials are random, not a satisfying witness.
@@ -341,7 +349,7 @@ def main() -> None:
                 result["value"] = None
                 result["error"] = "GPU result differs from the oracle: number withheld"
 
-    if world > 1 and not args.no_sharded_prove:
+    if world > 1 and not args.no_sharded_prove and not args.msm_only:
         # ---- prove() with every MSM sharded over the ranks (NTT / quotient replicated): typlonk_amd.dist.ShardedProver.
         # The block contains collectives, so the ranks AGREE on success before entering it and after it: a failure on
         # one rank (OOM, HIP error) must not leave its peers blocked in an all-gather.  A rank that fails inside the

@@ -3,6 +3,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r2p; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_msm -- python3 bench.py --steps 20 --warmup 5 --msm-only > $O/bench_msm_only.json 2> $O/bench_msm.err
 REPS=10 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/msm_loop.py > $O/pmc_fetch.log 2>&1
 REPS=10 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 tools/msm_loop.py > $O/pmc_write.log 2>&1
 REPS=10 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 tools/msm_loop.py > $O/pmc_sq.log 2>&1
