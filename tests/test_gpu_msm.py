@@ -172,7 +172,7 @@ def test_srs_generate_matches_reference_faithful_generator(ctx):
     ctx.srs_free(sid)
 
 
-@pytest.mark.parametrize("log_m,delta", [(16, 0), (16, -1), (20, 0), (20, -3)])
+@pytest.mark.parametrize("log_m,delta", [(16, 0), (16, -1), (20, 0), (20, -3), (20, -1), (22, 0), (22, -3)])
 def test_commit_identity_large(ctx, log_m, delta):
     """BASELINE configs 2-3 sizes (and the n-1 / n-3 lengths prove() uses): commit(p) == [p(s)]G,
     s = 2, SRS generated on the device, checked with the C oracle's Horner + scalar mul."""
@@ -188,6 +188,19 @@ def test_commit_identity_large(ctx, log_m, delta):
     out, inf = ctx.msm(sid, sc)
     exp, einf = CO.g1_mul_generator(CO.poly_eval(sc, s_limbs))
     assert (out == exp).all() and inf == einf
+    if log_m >= 20:
+        # the same with fixed-base tables (13 pre-shifted copies of the SRS): the configuration bench.py and the prover use,
+        # stand-alone (chunked) and inside a batch (not chunked)
+        ctx.srs_precompute(sid, 20)
+        out, inf = ctx.msm(sid, sc)
+        assert (out == exp).all() and inf == einf
+        buf = ctx.alloc(m)
+        buf.upload(sc)
+        res = ctx.msm_batch_devptr(sid, [buf.devptr, buf.devptr, buf.devptr], [m, m - 1, m])
+        assert (res[0][0] == exp).all() and res[0][1] == einf and (res[2][0] == exp).all()
+        exp1, einf1 = CO.g1_mul_generator(CO.poly_eval(sc[:m - 1], s_limbs))
+        assert (res[1][0] == exp1).all() and res[1][1] == einf1
+        buf.free()
     ctx.srs_free(sid)
 
 
