@@ -134,6 +134,8 @@ struct typlonk_ctx {
     // bit 2 = first opening MSMs of round 3 submitted before the quotient
     int prover_overlap = 3;   // measured (profiles/r02_ab_prover_overlap.txt): bits 0-1 gain ~1 %, bit 2 loses ~1 %
     int msm_chunks = 0;            // TYPLONK_MSM_CHUNKS: chunks of a stand-alone MSM (0 = choose by length)
+    int prover_rounds_active = 0;  // > 0 while a typlonk_prover_round* call is running (ProverRound)
+    bool ntt_big_tiles = true;     // TYPLONK_NTT_BIG=0: always 1024-element tiles (three passes at 2^20)
     bool ntt_full_tables = true;   // TYPLONK_NTT_FULL_TABLES=0: compose twiddles / coset powers from two-level tables
     uint32_t ntt_full_max_log = 24;
     bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
@@ -185,6 +187,11 @@ struct DevGuard {
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
+};
+struct ProverRound {
+    typlonk_ctx* ctx;
+    explicit ProverRound(typlonk_ctx* c) : ctx(c) { ++c->prover_rounds_active; }
+    ~ProverRound() { --ctx->prover_rounds_active; }
 };
 // Stage events are per call: composite calls switch them off for their inner calls and restore on every exit path.
 struct ProfilingOff {
@@ -397,8 +404,13 @@ int evict_coset_tables(typlonk_ctx* ctx, const std::string& incoming_group, size
     }
 }
 
-void split_log(uint32_t L, uint32_t ks[4], uint32_t* P) {
+// big = 4096-element tiles (1024 threads, 128 KiB of LDS): sub-transforms of 2^10 points with 4 adjacent columns, so a
+// 2^20 transform needs two passes instead of three -- one load/store round and one inter-pass twiddle fewer.  Only 2^20:
+// that is 256 tiles, one per CU; 2^17..2^19 would leave most of the chip idle (measured: 2^19 0.097 -> 0.132 ms) and
+// 2^21.. do not fit (2^11-point sub-transforms x 4 columns = 256 KiB).
+void split_log(uint32_t L, uint32_t ks[4], uint32_t* P, bool big = false) {
     uint32_t p = L <= 10 ? 1 : (L <= 16 ? 2 : (L <= 24 ? 3 : 4));
+    if (big && L == 20) p = 2;
     *P = p;
     for (uint32_t i = 0; i < p; ++i) ks[i] = L / p + (i < L % p ? 1 : 0);
 }
@@ -419,7 +431,12 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     }
     const uint64_t N = 1ull << log_n;
     uint32_t ks[4], P;
-    split_log(log_n, ks, &P);
+    // (not inside a prover round: there the 144 KiB workgroups crowd out the LDS of the MSM lanes' sort kernels running
+    // beside them -- prove() 38.1 -> 38.3 ms in the same-box A/B)
+    const bool big = ctx->ntt_big_tiles && log_n == 20 && ctx->prover_rounds_active == 0;
+    const uint32_t cap = big ? 12 : 10;        // log2 of the tile capacity
+    const unsigned threads = big ? 1024 : 256;
+    split_log(log_n, ks, &P, big);
     const std::string dir = inverse ? "i" : "f";
 
     Fr* scratch = nullptr;
@@ -493,7 +510,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
                                 a.S, row_len, &full);
             if (rc) return rc;
             a.tw_full = full.d;
-            logT = std::min<uint32_t>(10 - k, ilog2_u64(a.S));
+            logT = std::min<uint32_t>(cap - k, ilog2_u64(a.S));
         } else {
             const uint64_t N1 = 1ull << ks[0];
             a.N1 = (P == 1) ? 1 : N1;
@@ -501,7 +518,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             a.N2 = (P >= 3) ? (1ull << ks[1]) : 1;
             a.N3 = (P == 4) ? (1ull << ks[2]) : 1;
             a.out_stride = N / M;
-            logT = (P == 1) ? 0 : std::min<uint32_t>(10 - k, ks[0]);
+            logT = (P == 1) ? 0 : std::min<uint32_t>(cap - k, ks[0]);
             a.post_lo = post_lo.d;
             a.post_hi = post_hi.d;
             a.post_h = post_h;
@@ -534,7 +551,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         {
             static const char* names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
             StageTimer st(ctx, names[p]);
-            launch_ntt_pass(a, (unsigned)blocks, lds, ctx->stream);
+            launch_ntt_pass(a, (unsigned)blocks, threads, lds, ctx->stream);
         }
         HIPCHK(hipGetLastError());
         rows *= M;
@@ -1026,6 +1043,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_INFLIGHT")) ctx->msm_inflight = atoi(e);
     if (const char* e = getenv("TYPLONK_PROVER_OVERLAP")) ctx->prover_overlap = atoi(e);
     if (const char* e = getenv("TYPLONK_MSM_CHUNKS")) ctx->msm_chunks = std::max(0, std::min(atoi(e), MSM_MAX_CHUNKS));
+    if (const char* e = getenv("TYPLONK_NTT_BIG")) ctx->ntt_big_tiles = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_NTT_FULL_TABLES")) ctx->ntt_full_tables = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_NTT_FULL_MAX_LOG")) ctx->ntt_full_max_log = (uint32_t)atoi(e);
     *out = ctx;
@@ -1680,6 +1698,7 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     p->r = c;
     hipStream_t s = ctx->stream;
     ProfilingOff prof_off(ctx);  // stage events are per call
+    ProverRound in_round(ctx);
     // a, b, c = interpolate(columns) (proof.rs:50); the column values themselves are kept for round 2
     // (proof.rs:113-115 recomputes them with three forward FFTs).  Each commitment (round1, proof.rs:107-110) is
     // submitted to its own lane as soon as its polynomial exists, so the next interpolation and the coset transforms
@@ -1737,6 +1756,7 @@ int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint6
     const typlonk_buf* sp[3] = {&sb[0], &sb[1], &sb[2]};
     typlonk_buf zb{p->z, n};
     ProfilingOff prof_off(ctx);  // stage events are per call
+    ProverRound in_round(ctx);
     int rc = typlonk_grand_product_dev(ctx, wp, sp, beta, gamma, cosets, p->log_n, &zb);  // proof.rs:119-120
     if (!rc) rc = ntt_run(ctx, p->z, p->log_n, 1, nullptr, false);                          // :127-128
     if (!rc) {
@@ -1773,6 +1793,7 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
     memcpy(al.v, alpha, 32);
     memcpy(ze.v, zeta, 32);
     ProfilingOff prof_off(ctx);  // stage events are per call
+    ProverRound in_round(ctx);
     const SrsEntry* srs = nullptr;
     int rc = msm_validate(ctx, p->srs_id, n, &srs);
     if (rc) return rc;
@@ -1933,6 +1954,7 @@ int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlon
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = p->n;
     ProfilingOff prof_off(ctx);  // stage events are per call
+    ProverRound in_round(ctx);
     // F = a + v b + v^2 c + v^3 Z + v^4 r; division by (X - zeta) is linear, so its witness is
     // sum_i v^i W_i of the six-opening proof
     LincombArgs la{};

@@ -66,7 +66,7 @@ struct LincombArgs {
 void launch_eval_multi(const Fr* const* polys, uint32_t count, uint64_t m, const Fr& z, Fr* blocks, Fr* y, hipStream_t s);
 void launch_lincomb(const LincombArgs& a, hipStream_t s);
 
-void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s);
+void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);
 void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n, Fr* out, hipStream_t s);
 
 void launch_convert_points(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);

@@ -35,9 +35,10 @@ __device__ __forceinline__ Fr ntt_pow2l(const Fr* lo, const Fr* hi, uint32_t h, 
     return fe_mul(ntt_ld(lo + (e & ((1ull << h) - 1))), ntt_ld(hi + (e >> h)));
 }
 
-constexpr int NTT_THREADS = 256;
-
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
+// 256 threads on tiles of <= 1024 elements (32 KiB of LDS), or 1024 threads on tiles of <= 4096 elements (128 KiB:
+// one workgroup per CU) when a 2^17..2^20 transform is done in two passes instead of three (capi.hip, ntt_run)
+__global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
+    const uint32_t NTT_THREADS = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
     const uint32_t k = a.k, logT = a.logT;
     const uint32_t M = 1u << k, T = 1u << logT, E = M << logT;
@@ -154,8 +155,17 @@ void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, u
     hipLaunchKernelGGL(ntt_full_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, h, S, n, out);
 }
 
-void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(NTT_THREADS), lds_bytes, s, a);
+void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s) {
+    if (lds_bytes > 64 * 1024) {
+        // more than the default dynamic-LDS limit: opt in once (gfx950 has 160 KiB per workgroup)
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(threads), lds_bytes, s, a);
 }
 
 }  // namespace ty
