@@ -219,13 +219,13 @@ def main() -> None:
         result["ntt"] = {"log_n": log_n, "ms": tn * 1e3, "kernel_ms": kern / reps,
                          "algorithmic_GBps": 64.0 * n / (kern / reps * 1e-3) / 1e9,
                          "frac_of_hbm_peak": 64.0 * n / (kern / reps * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        try:   # PMC traffic of one pass (three passes per 2^20 transform), profiles/r02_pmc_ntt.json
+        try:   # PMC traffic of one pass (two passes per 2^20 transform, three at 2^22), profiles/r02_pmc_ntt.json
             with open(os.path.join(ROOT, "profiles", "r02_pmc_ntt.json")) as f:
                 pm = json.load(f).get(f"ntt_pass_kernel n=2^{log_n}")
             if pm:
                 result["ntt"]["pmc_traffic_bytes_per_pass"] = pm["traffic_bytes_per_pass"]
                 result["ntt"]["note"] = ("VALU-bound (80 % Fr multiplications, DESIGN.md section 5): the algorithmic figure "
-                                         "counts 64 B per element once; the passes actually move ~4x that")
+                                         "counts 64 B per element once; the two passes of a 2^20 transform move ~2.8x that")
         except Exception:
             pass
 
