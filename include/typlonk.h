@@ -222,6 +222,30 @@ int typlonk_prover_round3_evals(typlonk_prover* p, const uint64_t alpha[4], cons
 int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlonk_proof_batched* out);
 void typlonk_prover_free(typlonk_prover* p);
 
+/* ---- prove(): plonk::proof::prove in ONE call (/root/reference/plonk/src/proof.rs:26-57, 96-194), the Fiat-Shamir
+ * transcript included.  The rounds above are driven with the challenges the reference's ChallengeGenerator would
+ * squeeze (/root/reference/plonk/src/proof/challenges.rs:9-46; restated natively in csrc/transcript.hpp from the
+ * published behaviour of ark-serialize, blake2, rand and ark-ff -- not verifiable against Rust in this image):
+ * (beta, gamma) from [a], [b], [c] (proof.rs:111), (alpha, zeta) from [a], [b], [c], [Z] (:133-136).  `out` holds the
+ * fields of the reference's Proof (proof.rs:65-95): the three wire commitments with their openings, the permutation
+ * commitment with its two openings, evaluation_point = zeta, the three quotient-slice commitments and the opening of
+ * r; the challenges are returned too (the reference's verifier recomputes them, :236-246).
+ * wire_evals / pi_evals / circuit / SRS exactly as for typlonk_prover_round1; cosets as for round2.
+ * Returns TYPLONK_ERR_UNSATISFIED (with `out` filled) when r(zeta) != 0. */
+typedef struct typlonk_proof {
+    uint64_t commit_xy[3][12];  /* [a], [b], [c] */
+    uint8_t commit_inf[3];
+    uint64_t z_xy[12];          /* [Z] */
+    uint8_t z_inf;
+    typlonk_proof_tail tail;    /* [t_lo], [t_mid], [t_hi]; witnesses a, b, c, Z at zeta, Z at zeta*w, r; the six evaluations */
+    uint64_t beta[4], gamma[4], alpha[4], zeta[4];
+} typlonk_proof;
+int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
+                  const typlonk_buf* pi_evals, const uint64_t cosets[3][4], typlonk_proof* out);
+/* The transcript alone (host-only, no GPU): digest `count` commitments (C-ABI form) in order and squeeze
+ * n_challenges Fr elements (4 Montgomery limbs each) -- ChallengeGenerator::with_digest(..).generate_challenges::<N>(). */
+int typlonk_transcript_challenges(const uint64_t* xy, const uint8_t* inf, size_t count, size_t n_challenges, uint64_t* out);
+
 /* ---- device-resident Fr vectors (so an iNTT result feeds an MSM without crossing PCIe) ---------- */
 int typlonk_buf_alloc(typlonk_ctx* ctx, size_t n_elems, typlonk_buf** out);
 int typlonk_buf_free(typlonk_ctx* ctx, typlonk_buf* buf);

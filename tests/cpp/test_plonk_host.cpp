@@ -1,0 +1,117 @@
+// prove() through the C++ host mirror (typlonk_amd/host/typlonk_host.hpp, plonk::CompiledCircuit::prove ->
+// typlonk_prove) -- needs a GPU.  The circuit is the reference README's idiom `a.clone() * a` repeated
+// (/root/reference/README.md:20): a chain of n - 3 squarings, tables as the reference's front end would hand them over
+// (selector rows builder.rs:318-324, copy constraints as sigma = k_{i'} w^{j'}, permutation/src/lib.rs:108-119,
+// cosets 2, 3, 4 :141-154).  Checked like the reference's tests can be checked without a pairing: r(zeta) == 0
+// (proof.rs:234-235) and every KZG opening in its trapdoor form (s - z) W == C - y G (kzg/src/lib.rs:66-81 with the
+// secret known), plus the linearisation identity through the commitments' homomorphism.  A witness with one wrong cell
+// must throw (the reference panics).
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../typlonk_amd/host/typlonk_host.hpp"
+
+using namespace typlonk;
+
+#define REQUIRE(c)                                                          \
+    do {                                                                    \
+        if (!(c)) {                                                         \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c);      \
+            std::exit(1);                                                   \
+        }                                                                   \
+    } while (0)
+
+static bool opening_holds(const Context& ctx, const kzg::G1Point& G, const Fr& s, const kzg::KzgCommitment& C,
+                          const kzg::KzgOpening& o, const Fr& z) {
+    const kzg::G1Point lhs = kzg::g1_mul(ctx, o.p, s - z);
+    const kzg::G1Point rhs = kzg::g1_add(C.p, kzg::g1_neg(ctx, kzg::g1_mul(ctx, G, o.y)));
+    return lhs == rhs;
+}
+
+int main() {
+    Context ctx(0);
+    const uint32_t log_n = 6;
+    const size_t n = (size_t)1 << log_n, gates = n - 3;
+    const Fr s(0x5EC2E7);
+    kzg::Srs srs = kzg::Srs::from_secret(ctx, s, gates);
+    REQUIRE(srs.len() == n);  // gates + 3
+    const poly::Radix2EvaluationDomain domain(ctx, n);
+    REQUIRE(domain.size() == n);
+
+    // ---- the tables of the compiled circuit ----
+    std::vector<Fr> sel[5];
+    for (auto& v : sel) v.assign(n, Fr::zero());
+    for (size_t j = 0; j < gates; ++j) {
+        sel[2][j] = Fr::one();  // q_o
+        sel[3][j] = Fr::one();  // q_m
+    }
+    const Fr cosets[3] = {Fr(2), Fr(3), Fr(4)};
+    std::vector<size_t> perm(3 * n);
+    for (size_t i = 0; i < 3 * n; ++i) perm[i] = i;
+    auto cyc = [&](std::vector<size_t> cells) {
+        for (size_t u = 0; u < cells.size(); ++u) perm[cells[u]] = cells[(u + 1) % cells.size()];
+    };
+    cyc({0, n});                                                     // a_0 ~ b_0
+    for (size_t j = 0; j + 1 < gates; ++j) cyc({2 * n + j, j + 1, n + j + 1});  // c_j ~ a_{j+1} ~ b_{j+1}
+    std::vector<Fr> roots(n);
+    for (size_t j = 0; j < n; ++j) roots[j] = domain.element(j);
+    std::vector<Fr> sigma[3];
+    for (int i = 0; i < 3; ++i) {
+        sigma[i].resize(n);
+        for (size_t j = 0; j < n; ++j) {
+            const size_t to = perm[j + i * n];
+            sigma[i][j] = cosets[to / n] * roots[to % n];
+        }
+    }
+    plonk::CompiledCircuit circuit(srs, log_n, sel, sigma, cosets);
+    REQUIRE(circuit.rows() == n);
+
+    // ---- a satisfying witness: x_{j+1} = x_j^2, three blinding rows per column (proof.rs:43-49) ----
+    std::vector<Fr> advice[3];
+    Fr x(3);
+    for (size_t j = 0; j < gates; ++j) {
+        advice[0].push_back(x);
+        advice[1].push_back(x);
+        x = x * x;
+        advice[2].push_back(x);
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) advice[i].push_back(Fr(1000 + 17 * i + 5 * k));
+    const plonk::Proof proof = circuit.prove(advice);
+    std::printf("prove ok\n");
+
+    // ---- checks ----
+    REQUIRE(proof.r.eval().is_zero());  // proof.rs:234-235
+    const kzg::G1Point G = srs.g1_ref()[0];
+    const Fr zeta = proof.evaluation_point;
+    const Fr zw = zeta * domain.element(1);
+    REQUIRE(opening_holds(ctx, G, s, proof.a_commit, proof.a, zeta));
+    REQUIRE(opening_holds(ctx, G, s, proof.b_commit, proof.b, zeta));
+    REQUIRE(opening_holds(ctx, G, s, proof.c_commit, proof.c, zeta));
+    REQUIRE(opening_holds(ctx, G, s, proof.permutation.commitment, proof.permutation.z, zeta));
+    REQUIRE(opening_holds(ctx, G, s, proof.permutation.commitment, proof.permutation.zw, zw));
+    std::printf("openings ok\n");
+    // the wire commitments are what KzgScheme::commit gives for the interpolated columns (proof.rs:50, 107-110)
+    kzg::KzgScheme scheme(srs);
+    REQUIRE(scheme.commit(poly::interpolate(advice[0], domain)) == proof.a_commit);
+    REQUIRE(scheme.commit(poly::interpolate(advice[2], domain)) == proof.c_commit);
+    // and the evaluations are the polynomials' values at zeta
+    REQUIRE(poly::interpolate(advice[1], domain).evaluate(zeta) == proof.b.eval());
+    std::printf("commitments ok\n");
+    // same witness, same proof (deterministic transcript)
+    const plonk::Proof again = circuit.prove(advice);
+    REQUIRE(again.permutation.commitment == proof.permutation.commitment && again.t[2] == proof.t[2] && again.r.p == proof.r.p);
+    // one wrong cell: gate 5 no longer holds
+    std::vector<Fr> bad[3] = {advice[0], advice[1], advice[2]};
+    bad[2][5] = bad[2][5] + Fr::one();
+    bool threw = false;
+    try {
+        (void)circuit.prove(bad);
+    } catch (const std::runtime_error& e) {
+        threw = std::string(e.what()).find("witness") != std::string::npos;
+    }
+    REQUIRE(threw);
+    std::printf("bad witness rejected ok\n");
+    std::printf("all ok\n");
+    return 0;
+}

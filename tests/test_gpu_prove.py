@@ -351,3 +351,40 @@ def test_prove_with_the_transcript_and_verify_by_recomputing_challenges(ctx):
         b.free()
     ctx.circuit_free(cid)
     ctx.srs_free(sid)
+
+
+@pytest.mark.parametrize("log_n", [4, 7])
+def test_native_prove_equals_the_round_by_round_flow(ctx, log_n):
+    """typlonk_prove (one native call, transcript in csrc/transcript.hpp) returns exactly what Context.prove assembles
+    from the three rounds with the Python statement of the transcript -- commitments, witnesses, evaluations -- and the
+    challenges it used are the ones recomputed from its own commitments (verify_challenges, proof.rs:236-246)"""
+    from typlonk_amd import transcript as T
+    from typlonk_amd.capi import ERR_UNSATISFIED, TyplonkError
+
+    n, cols, q_evals, perm, cid = _setup(ctx, log_n)
+    sid = ctx.srs_generate(_limbs(0x1CEB00DA), n + 3)
+    wires = [_up(ctx, c, n) for c in cols]
+    ks = [_limbs(k) for k in PO.COSETS]
+    ref = ctx.prove(sid, cid, wires, None, ks)          # Python transcript between the rounds
+    got = ctx.prove_native(sid, cid, wires, None, ks)
+    same = lambda a, b: bool((np.asarray(a[0]) == np.asarray(b[0])).all() and int(a[1]) == int(b[1]))   # noqa: E731
+    for key in ("commit", "t_commit", "witness"):
+        assert len(got[key]) == len(ref[key]) and all(same(a, b) for a, b in zip(got[key], ref[key])), key
+    assert same(got["z_commit"], ref["z_commit"])
+    assert all((a == b).all() for a, b in zip(got["evals"], ref["evals"]))
+    assert not got["evals"][5].any()
+    beta, gamma = T.challenge12(got["commit"])
+    alpha, zeta = T.challenge34(got["commit"] + [got["z_commit"]])
+    for name, want in (("beta", beta), ("gamma", gamma), ("alpha", alpha), ("zeta", zeta)):
+        assert (got["challenges"][name] == want).all(), name
+    # a witness that violates a gate: the reference panics, the native call reports it
+    bad_cols = [list(c) for c in cols]
+    bad_cols[2][1] = (bad_cols[2][1] + 1) % O.R
+    bad = [_up(ctx, c, n) for c in bad_cols]
+    with pytest.raises(TyplonkError) as e:
+        ctx.prove_native(sid, cid, bad, None, ks)
+    assert e.value.code == ERR_UNSATISFIED
+    for b in wires + bad:
+        b.free()
+    ctx.circuit_free(cid)
+    ctx.srs_free(sid)

@@ -225,3 +225,28 @@ def test_transcript_building_blocks():
     assert all(val(x) < T.FR_MODULUS for x in a + c) and val(a[0]) != val(c[0]) and val(a[0]) != val(a[1])
     # seed expansion: 32 bytes, a function of the seed
     assert len(T.seed_from_u64(0)) == 32 and T.seed_from_u64(0) != T.seed_from_u64(1)
+
+
+def test_native_transcript_equals_the_python_statement(built):
+    """typlonk_transcript_challenges (csrc/transcript.hpp: Blake2b-512, PCG32 seed expansion, ChaCha12, Fr::rand,
+    serialize_unchecked) against typlonk_amd/transcript.py (hashlib Blake2b + an independent ChaCha): two restatements
+    of plonk/src/proof/challenges.rs:9-46 written separately must agree bit for bit -- 0..6 commitments (0, 96, ... 576
+    bytes: below, at and across Blake2b's 128-byte blocks), the point at infinity included"""
+    import random
+
+    from typlonk_amd import transcript as T
+    from typlonk_amd.capi import transcript_challenges
+
+    rnd = random.Random(77)
+    pts = []
+    for i in range(6):
+        p = None if i == 3 else O.g1_mul(O.G1, rnd.randrange(1, O.R))
+        limbs, f = O.g1_to_limbs(p)
+        pts.append((np.array(limbs, dtype=np.uint64), f))
+    for k in range(0, 7):
+        for n in (1, 2, 5):
+            a = transcript_challenges(pts[:k], n)
+            b = T.ChallengeGenerator.with_digest(pts[:k]).generate_challenges(n)
+            assert len(a) == len(b) == n and all((x == y).all() for x, y in zip(a, b)), (k, n)
+            for x in a:   # a valid Montgomery residue: the limbs read as an integer are below r
+                assert sum(int(v) << (64 * i) for i, v in enumerate(x)) < O.R

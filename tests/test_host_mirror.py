@@ -27,6 +27,15 @@ def test_reference_kzg_and_l0_tests_cpp(built):
         assert t in out
 
 
+@pytest.mark.gpu
+def test_prove_through_the_cpp_mirror(built):
+    """plonk::CompiledCircuit::prove (typlonk_host.hpp -> typlonk_prove): squaring chain built in C++, r(zeta) == 0, every
+    opening in its trapdoor form, a wrong witness throws"""
+    out = _run("test_plonk_host")
+    for t in ("prove ok", "openings ok", "commitments ok", "bad witness rejected ok"):
+        assert t in out
+
+
 def test_poly_glue_under_address_and_ub_sanitizers(built, tmp_path):
     """the host-side C++ (typlonk_host.hpp + the shared field headers) compiled with ASan + UBSan on the CPU build
     (GPU sanitizers are not available on this pool): no report, same answers"""

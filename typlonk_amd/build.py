@@ -2,7 +2,7 @@
 
   typlonk_amd/libtyplonk_hip.so   HIP kernels + C ABI (include/typlonk.h)       -- hipcc
   tests/cpp/libff_host_shim.so    host shim over the shared arithmetic headers  -- g++
-  tests/cpp/test_{poly,kzg}_host  tests of the C++ host mirror (typlonk_amd/host) -- g++
+  tests/cpp/test_{poly,kzg,plonk}_host  tests of the C++ host mirror (typlonk_amd/host) -- g++
 
 Every target is rebuilt only when one of its sources is newer than the output.
 """
@@ -80,7 +80,7 @@ def build_host_tests(force: bool = False) -> list[str]:
     """test binaries of the C++ host mirror (typlonk_amd/host/typlonk_host.hpp), linked to the HIP library"""
     outs = []
     hdr = [os.path.join(ROOT, "typlonk_amd", "host", "typlonk_host.hpp"), os.path.join(CSRC, "ff.hpp"), LIB]
-    for name in ("test_poly_host", "test_kzg_host"):
+    for name in ("test_poly_host", "test_kzg_host", "test_plonk_host"):
         src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
         out = os.path.join(ROOT, "tests", "cpp", name)
         if force or _stale(out, [src] + hdr):

@@ -21,7 +21,8 @@ SYMBOLS = [
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_precompute", "typlonk_srs_set_shard", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
     "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
-    "typlonk_prover_round3", "typlonk_prover_round3_evals", "typlonk_prover_round4_batched", "typlonk_prover_free", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_prover_round3", "typlonk_prover_round3_evals", "typlonk_prover_round4_batched", "typlonk_prover_free",
+    "typlonk_prove", "typlonk_transcript_challenges", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
@@ -56,6 +57,13 @@ class ProofBatched(C.Structure):
     """typlonk_proof_batched"""
     _fields_ = [("t_xy", (C.c_uint64 * 12) * 3), ("t_inf", C.c_uint8 * 3), ("w_xy", (C.c_uint64 * 12) * 2),
                 ("w_inf", C.c_uint8 * 2)]
+
+
+class Proof(C.Structure):
+    """typlonk_proof"""
+    _fields_ = [("commit_xy", (C.c_uint64 * 12) * 3), ("commit_inf", C.c_uint8 * 3), ("z_xy", C.c_uint64 * 12),
+                ("z_inf", C.c_uint8), ("tail", ProofTail), ("beta", C.c_uint64 * 4), ("gamma", C.c_uint64 * 4),
+                ("alpha", C.c_uint64 * 4), ("zeta", C.c_uint64 * 4)]
 
 
 _lib = None
@@ -105,6 +113,8 @@ def load_library() -> C.CDLL:
     lib.typlonk_prover_round3.argtypes = [vp, u64p, u64p, C.POINTER(ProofTail)]
     lib.typlonk_prover_round3_evals.argtypes = [vp, u64p, u64p, C.POINTER(ProofEvals)]
     lib.typlonk_prover_round4_batched.argtypes = [vp, u64p, C.POINTER(ProofBatched)]
+    lib.typlonk_prove.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), vp, C.POINTER((C.c_uint64 * 4) * 3), C.POINTER(Proof)]
+    lib.typlonk_transcript_challenges.argtypes = [u64p, u8p, C.c_size_t, C.c_size_t, u64p]
     lib.typlonk_prover_free.argtypes = [vp]
     lib.typlonk_prover_free.restype = None
     lib.typlonk_circuit_load.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -156,6 +166,22 @@ def g1_sum_host(xy, inf=None):
     if rc:
         raise TyplonkError(rc, lib.typlonk_strerror(rc).decode())
     return out, int(oinf[0])
+
+
+def transcript_challenges(points, n: int):
+    """typlonk_transcript_challenges (host-only): points = [(xy[12], inf), ...] -> n challenges (4 limbs each)"""
+    lib = load_library()
+    k = len(points)
+    xy = np.zeros((max(k, 1), 12), dtype=np.uint64)
+    inf = np.zeros(max(k, 1), dtype=np.uint8)
+    for i, (p, f) in enumerate(points):
+        xy[i] = np.asarray(p, dtype=np.uint64).reshape(12)
+        inf[i] = f
+    out = np.zeros((n, 4), dtype=np.uint64)
+    rc = lib.typlonk_transcript_challenges(_u64p(xy), _u8p(inf), k, n, _u64p(out))
+    if rc:
+        raise TyplonkError(rc, lib.typlonk_strerror(rc).decode())
+    return [out[i].copy() for i in range(n)]
 
 
 class DeviceBuffer:
@@ -425,6 +451,27 @@ class Context:
         return {
             "commit": commits, "z_commit": (zxy, int(zinf[0])), "t_commit": tw[:3], "witness": tw[3:],
             "evals": [np.array(tail.evals[i], dtype=np.uint64) for i in range(6)],
+        }
+
+    def prove_native(self, sid: int, circuit: int, wire_evals, pi_evals, cosets):
+        """typlonk_prove: the whole prove() in one native call, transcript included.  Same dict as prove() plus the
+        challenges; raises TyplonkError(ERR_UNSATISFIED) for a witness that does not satisfy the circuit."""
+        w = (C.c_void_p * 3)(*[b.handle.value for b in wire_evals])
+        ks = ((C.c_uint64 * 4) * 3)()
+        for i in range(3):
+            for j, limb in enumerate(np.asarray(cosets[i], dtype=np.uint64).reshape(4)):
+                ks[i][j] = int(limb)
+        pr = Proof()
+        self._chk(self.lib.typlonk_prove(self.h, sid, circuit, w, pi_evals.handle if pi_evals is not None else None,
+                                         C.byref(ks), C.byref(pr)))
+        t = pr.tail
+        return {
+            "commit": [(np.array(pr.commit_xy[i], dtype=np.uint64), int(pr.commit_inf[i])) for i in range(3)],
+            "z_commit": (np.array(pr.z_xy, dtype=np.uint64), int(pr.z_inf)),
+            "t_commit": [(np.array(t.t_xy[i], dtype=np.uint64), int(t.t_inf[i])) for i in range(3)],
+            "witness": [(np.array(t.w_xy[i], dtype=np.uint64), int(t.w_inf[i])) for i in range(6)],
+            "evals": [np.array(t.evals[i], dtype=np.uint64) for i in range(6)],
+            "challenges": {k: np.array(getattr(pr, k), dtype=np.uint64) for k in ("beta", "gamma", "alpha", "zeta")},
         }
 
     def circuit_load(self, log_n: int, selectors, sigma) -> int:

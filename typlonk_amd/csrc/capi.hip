@@ -5,6 +5,7 @@
 #include "../../include/typlonk.h"
 #include "g1.hpp"
 #include "launch.hpp"
+#include "transcript.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -1992,6 +1993,40 @@ int typlonk_prover_round4_batched(typlonk_prover* p, const uint64_t v[4], typlon
             p->round = 4;
         }
     }
+    return rc;
+}
+
+int typlonk_transcript_challenges(const uint64_t* xy, const uint8_t* inf, size_t count, size_t n_challenges, uint64_t* out) {
+    if ((!xy && count) || (!out && n_challenges)) return TYPLONK_ERR_INVALID_ARG;
+    ChallengeGenerator g;
+    for (size_t i = 0; i < count; ++i) g.digest(xy + 12 * i, inf ? inf[i] : 0);
+    g.generate(n_challenges, out);
+    return TYPLONK_OK;
+}
+
+int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
+                  const typlonk_buf* pi_evals, const uint64_t cosets[3][4], typlonk_proof* out) {
+    if (!ctx || !wire_evals || !cosets || !out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    typlonk_prover* p = nullptr;
+    int rc = typlonk_prover_round1(ctx, srs_id, circuit_id, wire_evals, pi_evals, &p, out->commit_xy, out->commit_inf);
+    if (rc) return rc;
+    // (beta, gamma) <- H([a], [b], [c])                                                   proof.rs:111
+    ChallengeGenerator g;
+    for (int i = 0; i < 3; ++i) g.digest(out->commit_xy[i], out->commit_inf[i]);
+    uint64_t ch[8];
+    g.generate(2, ch);
+    memcpy(out->beta, ch, 32);
+    memcpy(out->gamma, ch + 4, 32);
+    rc = typlonk_prover_round2(p, out->beta, out->gamma, cosets, out->z_xy, &out->z_inf);
+    if (!rc) {
+        // (alpha, zeta) <- H([a], [b], [c], [Z])                                          proof.rs:133-136
+        g.digest(out->z_xy, out->z_inf);
+        g.generate(2, ch);
+        memcpy(out->alpha, ch, 32);
+        memcpy(out->zeta, ch + 4, 32);
+        rc = typlonk_prover_round3(p, out->alpha, out->zeta, &out->tail);
+    }
+    typlonk_prover_free(p);
     return rc;
 }
 

@@ -10,6 +10,9 @@
 //   poly::Radix2EvaluationDomain / Evaluations::interpolate / evaluate_over_domain
 //                               call sites /root/reference/plonk/src/proof.rs:50,106,115 ;
 //                               plonk/src/builder.rs:70,85 ; plonk/src/utils.rs:150-159 (l0_poly)
+//   plonk::CompiledCircuit      /root/reference/plonk/src/lib.rs:19-35 (srs, domain, gate_constrains, copy_constrains)
+//   plonk::CompiledCircuit::prove / plonk::Proof
+//                               /root/reference/plonk/src/proof.rs:26-57, 65-95, 96-194 -> typlonk_prove
 //
 // Every group / transform operation goes to the GPU through the C ABI; the O(n) glue the reference
 // does on the CPU (Horner, synthetic division) is done on the CPU here too, with the library's own
@@ -298,4 +301,137 @@ inline G1Point g1_mul(const Context& ctx, const G1Point& p, const Fr& k) {
 inline G1Point g1_neg(const Context& ctx, const G1Point& p) { return g1_mul(ctx, p, -Fr::one()); }
 
 }  // namespace kzg
+
+namespace plonk {
+
+// plonk::proof::Proof (/root/reference/plonk/src/proof.rs:65-95)
+struct PermutationProof {
+    kzg::KzgCommitment commitment;
+    kzg::KzgOpening z, zw;
+};
+struct Proof {
+    kzg::KzgCommitment a_commit, b_commit, c_commit;
+    kzg::KzgOpening a, b, c;          // openings at evaluation_point
+    PermutationProof permutation;     // [Z], Z at zeta, Z at zeta * w
+    Fr evaluation_point;              // zeta
+    kzg::KzgCommitment t[3];          // quotient slices
+    kzg::KzgOpening r;                // linearisation polynomial at zeta: r.eval() == 0 for a valid proof
+    Fr beta, gamma, alpha;            // the challenges used (the reference's verifier recomputes them, :236-246)
+};
+
+// The prover-relevant part of plonk::CompiledCircuit (/root/reference/plonk/src/lib.rs:19-35): the SRS, the domain,
+// the five selector polynomials (gate_constrains, builder.rs:76-90) and the sigma columns with their cosets
+// (copy_constrains, permutation/src/lib.rs:141-154).  The tables come from the reference's front end
+// (CircuitDescription::build, out of scope here) as EVALUATIONS over the domain, exactly as builder.rs:85 interpolates
+// them; they are interpolated on the device once and cached for every later proof (typlonk_circuit_load).
+class CompiledCircuit {
+   public:
+    CompiledCircuit(const kzg::Srs& srs, uint32_t log_n, const std::vector<Fr> (&selector_evals)[5],
+                    const std::vector<Fr> (&sigma_evals)[3], const Fr (&cosets)[3])
+        : srs_(srs), log_n_(log_n), n_((size_t)1 << log_n) {
+        for (int i = 0; i < 3; ++i) cosets_[i] = cosets[i];
+        typlonk_ctx* c = srs.ctx().raw();
+        typlonk_buf* polys[8];
+        for (int k = 0; k < 8; ++k) {
+            const std::vector<Fr>& ev = k < 5 ? selector_evals[k] : sigma_evals[k - 5];
+            if (ev.size() != n_) throw std::runtime_error("circuit table must hold n evaluations");
+            polys[k] = upload(ev);
+            check(typlonk_ntt_fr_dev(c, polys[k], 0, log_n, 1, nullptr), c);  // interpolate(), builder.rs:85
+        }
+        const typlonk_buf* sel[5] = {polys[0], polys[1], polys[2], polys[3], polys[4]};
+        const typlonk_buf* sig[3] = {polys[5], polys[6], polys[7]};
+        const int rc = typlonk_circuit_load(c, sel, sig, log_n, &circuit_);
+        for (typlonk_buf* b : polys) typlonk_buf_free(c, b);
+        check(rc, c);
+    }
+    CompiledCircuit(const CompiledCircuit&) = delete;
+    ~CompiledCircuit() {
+        if (circuit_) typlonk_circuit_free(srs_.ctx().raw(), circuit_);
+    }
+    size_t rows() const { return n_; }
+
+    // CompiledCircuit::prove (proof.rs:26-57) from the point where the witness columns exist: `advice` = the three
+    // columns padded to n rows with their blinding rows (:43-49), `public_inputs` = the padded public-input column or
+    // empty for the all-zero one (:52-53).  A witness that does not satisfy the circuit throws (the reference panics).
+    Proof prove(const std::vector<Fr> (&advice)[3], const std::vector<Fr>& public_inputs = {}) const {
+        typlonk_ctx* c = srs_.ctx().raw();
+        typlonk_buf* w[3] = {nullptr, nullptr, nullptr};
+        typlonk_buf* pi = nullptr;
+        typlonk_proof raw;
+        int rc = TYPLONK_OK;
+        try {
+            for (int i = 0; i < 3; ++i) {
+                if (advice[i].size() != n_) throw std::runtime_error("witness column must hold n values");
+                w[i] = upload(advice[i]);
+            }
+            if (!public_inputs.empty()) {
+                if (public_inputs.size() != n_) throw std::runtime_error("public-input column must hold n values");
+                pi = upload(public_inputs);
+            }
+            uint64_t ks[3][4];
+            for (int i = 0; i < 3; ++i) std::memcpy(ks[i], cosets_[i].limbs(), 32);
+            const typlonk_buf* wc[3] = {w[0], w[1], w[2]};
+            rc = typlonk_prove(c, srs_.id(), circuit_, wc, pi, ks, &raw);
+        } catch (...) {
+            release(w, pi);
+            throw;
+        }
+        release(w, pi);
+        check(rc, c);
+        Proof p;
+        auto pt = [](const uint64_t xy[12], uint8_t inf) {
+            kzg::G1Point g;
+            std::memcpy(g.xy, xy, 96);
+            g.infinity = inf != 0;
+            return g;
+        };
+        auto fr = [](const uint64_t l[4]) {
+            Fr f;
+            std::memcpy(f.v.v, l, 32);
+            return f;
+        };
+        p.a_commit = {pt(raw.commit_xy[0], raw.commit_inf[0])};
+        p.b_commit = {pt(raw.commit_xy[1], raw.commit_inf[1])};
+        p.c_commit = {pt(raw.commit_xy[2], raw.commit_inf[2])};
+        const typlonk_proof_tail& t = raw.tail;
+        p.a = {pt(t.w_xy[0], t.w_inf[0]), fr(t.evals[0])};
+        p.b = {pt(t.w_xy[1], t.w_inf[1]), fr(t.evals[1])};
+        p.c = {pt(t.w_xy[2], t.w_inf[2]), fr(t.evals[2])};
+        p.permutation.commitment = {pt(raw.z_xy, raw.z_inf)};
+        p.permutation.z = {pt(t.w_xy[3], t.w_inf[3]), fr(t.evals[3])};
+        p.permutation.zw = {pt(t.w_xy[4], t.w_inf[4]), fr(t.evals[4])};
+        p.evaluation_point = fr(raw.zeta);
+        for (int i = 0; i < 3; ++i) p.t[i] = {pt(t.t_xy[i], t.t_inf[i])};
+        p.r = {pt(t.w_xy[5], t.w_inf[5]), fr(t.evals[5])};
+        p.beta = fr(raw.beta);
+        p.gamma = fr(raw.gamma);
+        p.alpha = fr(raw.alpha);
+        return p;
+    }
+
+   private:
+    typlonk_buf* upload(const std::vector<Fr>& v) const {
+        typlonk_ctx* c = srs_.ctx().raw();
+        typlonk_buf* b = nullptr;
+        check(typlonk_buf_alloc(c, v.size(), &b), c);
+        const int rc = typlonk_buf_upload(c, b, 0, v[0].limbs(), v.size());
+        if (rc < 0) {
+            typlonk_buf_free(c, b);
+            check(rc, c);
+        }
+        return b;
+    }
+    void release(typlonk_buf* (&w)[3], typlonk_buf* pi) const {
+        for (typlonk_buf* b : w)
+            if (b) typlonk_buf_free(srs_.ctx().raw(), b);
+        if (pi) typlonk_buf_free(srs_.ctx().raw(), pi);
+    }
+    const kzg::Srs& srs_;
+    uint32_t log_n_;
+    size_t n_;
+    Fr cosets_[3];
+    uint32_t circuit_ = 0;
+};
+
+}  // namespace plonk
 }  // namespace typlonk
