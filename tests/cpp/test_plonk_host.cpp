@@ -97,6 +97,11 @@ int main() {
     REQUIRE(scheme.commit(poly::interpolate(advice[2], domain)) == proof.c_commit);
     // and the evaluations are the polynomials' values at zeta
     REQUIRE(poly::interpolate(advice[1], domain).evaluate(zeta) == proof.b.eval());
+    // the circuit's fixed commitments (builder.rs:86; permutation/src/lib.rs:178-194) against commit(interpolate(table))
+    REQUIRE(circuit.fixed_commitments[3] == scheme.commit(poly::interpolate(sel[3], domain)));
+    REQUIRE(circuit.fixed_commitments[0] == scheme.commit(poly::interpolate(sel[0], domain)));   // the zero polynomial
+    REQUIRE(circuit.fixed_commitments[0].p.infinity);
+    for (int i = 0; i < 3; ++i) REQUIRE(circuit.sigma_commitments[i] == scheme.commit(poly::interpolate(sigma[i], domain)));
     std::printf("commitments ok\n");
     // same witness, same proof (deterministic transcript)
     const plonk::Proof again = circuit.prove(advice);

@@ -338,6 +338,30 @@ class CompiledCircuit {
             polys[k] = upload(ev);
             check(typlonk_ntt_fr_dev(c, polys[k], 0, log_n, 1, nullptr), c);  // interpolate(), builder.rs:85
         }
+        // the commitments of the fixed polynomials: [q_l] .. [q_c] (builder.rs:86) and [sigma_0..2], which the
+        // reference's verifier recomputes with three MSMs on EVERY verify() (permutation/src/lib.rs:178-194 via
+        // proof.rs:459) -- here once per circuit, one batch of eight MSMs straight from the interpolated buffers
+        {
+            const void* ptrs[8];
+            size_t lens[8];
+            uint64_t xy[8][12];
+            uint8_t inf[8];
+            for (int k = 0; k < 8; ++k) {
+                ptrs[k] = typlonk_buf_devptr(polys[k]);
+                lens[k] = n_;
+            }
+            const int rc = typlonk_msm_g1_batch_devptr(c, srs.id(), ptrs, lens, 8, &xy[0][0], inf);
+            if (rc < 0) {
+                for (typlonk_buf* b : polys) typlonk_buf_free(c, b);
+                check(rc, c);
+            }
+            for (int k = 0; k < 8; ++k) {
+                kzg::G1Point g;
+                std::memcpy(g.xy, xy[k], 96);
+                g.infinity = inf[k] != 0;
+                (k < 5 ? fixed_commitments[k] : sigma_commitments[k - 5]) = kzg::KzgCommitment{g};
+            }
+        }
         const typlonk_buf* sel[5] = {polys[0], polys[1], polys[2], polys[3], polys[4]};
         const typlonk_buf* sig[3] = {polys[5], polys[6], polys[7]};
         const int rc = typlonk_circuit_load(c, sel, sig, log_n, &circuit_);
@@ -349,6 +373,8 @@ class CompiledCircuit {
         if (circuit_) typlonk_circuit_free(srs_.ctx().raw(), circuit_);
     }
     size_t rows() const { return n_; }
+    kzg::KzgCommitment fixed_commitments[5];  // [q_l], [q_r], [q_o], [q_m], [q_c]  (GateConstrains::fixed_commitments)
+    kzg::KzgCommitment sigma_commitments[3];  // what CompiledPermutation::sigma_commitments returns
 
     // CompiledCircuit::prove (proof.rs:26-57) from the point where the witness columns exist: `advice` = the three
     // columns padded to n rows with their blinding rows (:43-49), `public_inputs` = the padded public-input column or
