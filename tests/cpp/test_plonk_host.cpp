@@ -103,6 +103,26 @@ int main() {
     REQUIRE(circuit.fixed_commitments[0].p.infinity);
     for (int i = 0; i < 3; ++i) REQUIRE(circuit.sigma_commitments[i] == scheme.commit(poly::interpolate(sigma[i], domain)));
     std::printf("commitments ok\n");
+    // ---- the reference's verifier with real pairings (proof.rs:195-235; kzg/src/lib.rs:66-81) ----
+    REQUIRE(scheme.verify(proof.a_commit, proof.a, zeta));
+    {
+        kzg::KzgOpening wrong = proof.a;
+        wrong.y = wrong.y + Fr::one();
+        REQUIRE(!scheme.verify(proof.a_commit, wrong, zeta));
+    }
+    REQUIRE(circuit.verify(proof));
+    {
+        plonk::Proof t = proof;                       // a tampered evaluation
+        t.b.y = t.b.y + Fr::one();
+        REQUIRE(!circuit.verify(t));
+        t = proof;                                    // a witness from another opening
+        t.r.p = proof.a.p;
+        REQUIRE(!circuit.verify(t));
+        t = proof;                                    // another evaluation point than the transcript's
+        t.evaluation_point = t.evaluation_point + Fr::one();
+        REQUIRE(!circuit.verify(t));
+    }
+    std::printf("verify ok\n");
     // same witness, same proof (deterministic transcript)
     const plonk::Proof again = circuit.prove(advice);
     REQUIRE(again.permutation.commitment == proof.permutation.commitment && again.t[2] == proof.t[2] && again.r.p == proof.r.p);

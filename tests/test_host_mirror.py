@@ -32,8 +32,21 @@ def test_prove_through_the_cpp_mirror(built):
     """plonk::CompiledCircuit::prove (typlonk_host.hpp -> typlonk_prove): squaring chain built in C++, r(zeta) == 0, every
     opening in its trapdoor form, a wrong witness throws"""
     out = _run("test_plonk_host")
-    for t in ("prove ok", "openings ok", "commitments ok", "bad witness rejected ok"):
+    for t in ("prove ok", "openings ok", "commitments ok", "verify ok", "bad witness rejected ok"):
         assert t in out
+
+
+def test_host_pairing_properties_and_equality_with_the_python_statement(built):
+    """pairing_host.hpp (C++) against oracle/pairing.py (Python big ints): written separately from the same published
+    definition, e(G1, G2) must agree coefficient by coefficient; the C++ side also checks order, bilinearity,
+    non-degeneracy and the product form the KZG verifier uses"""
+    from oracle import bls12_381 as O
+    from oracle import pairing as PR
+
+    out = _run("test_pairing_host")
+    assert "g2 ok" in out and "pairing ok" in out
+    got = [int(line.split("=")[1], 16) for line in out.splitlines() if line.startswith("e") and "=" in line]
+    assert got == PR.pairing(O.G1, PR.G2)
 
 
 def test_poly_glue_under_address_and_ub_sanitizers(built, tmp_path):

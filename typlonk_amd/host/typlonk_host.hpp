@@ -10,7 +10,11 @@
 //   poly::Radix2EvaluationDomain / Evaluations::interpolate / evaluate_over_domain
 //                               call sites /root/reference/plonk/src/proof.rs:50,106,115 ;
 //                               plonk/src/builder.rs:70,85 ; plonk/src/utils.rs:150-159 (l0_poly)
+//   kzg::KzgScheme::verify      /root/reference/kzg/src/lib.rs:66-81 (host pairing, pairing_host.hpp); Srs::g2 srs.rs:26-34
 //   plonk::CompiledCircuit      /root/reference/plonk/src/lib.rs:19-35 (srs, domain, gate_constrains, copy_constrains)
+//   plonk::CompiledCircuit::verify
+//                               /root/reference/plonk/src/proof.rs:195-281, 441-503 (verify, verify_challenges,
+//                               verify_openings, linearisation_commitment), plonk/src/utils.rs:96-109
 //   plonk::CompiledCircuit::prove / plonk::Proof
 //                               /root/reference/plonk/src/proof.rs:26-57, 65-95, 96-194 -> typlonk_prove
 //
@@ -26,6 +30,7 @@
 
 #include "../../include/typlonk.h"
 #include "../csrc/ff.hpp"
+#include "pairing_host.hpp"
 
 namespace typlonk {
 
@@ -203,7 +208,25 @@ class Srs {
         Srs r(ctx);
         r.len_ = gates + 3;
         check(typlonk_srs_generate(ctx.raw(), s.limbs(), 0, r.len_, &r.id_), ctx.raw());
+        // srs.rs:26-34: g2 = generator, g2s = [s] generator (host-side: the verifier's two G2 elements)
+        r.g2_ = pairing::g2_generator();
+        r.g2s_ = pairing::g2_mul(r.g2_, s.v);
+        r.has_g2_ = true;
         return r;
+    }
+    // an SRS loaded from points brings its G2 pair along (needed by KzgScheme::verify only)
+    void set_g2(const pairing::G2Affine& g2, const pairing::G2Affine& g2s) {
+        g2_ = g2;
+        g2s_ = g2s;
+        has_g2_ = true;
+    }
+    const pairing::G2Affine& g2() const {
+        if (!has_g2_) throw std::runtime_error("this SRS has no G2 elements");
+        return g2_;
+    }
+    const pairing::G2Affine& g2s() const {
+        if (!has_g2_) throw std::runtime_error("this SRS has no G2 elements");
+        return g2s_;
     }
     static Srs from_points(const Context& ctx, const std::vector<G1Point>& pts) {
         Srs r(ctx);
@@ -217,7 +240,7 @@ class Srs {
         check(typlonk_srs_load(ctx.raw(), xy.data(), inf.data(), pts.size(), &r.id_), ctx.raw());
         return r;
     }
-    Srs(Srs&& o) noexcept : ctx_(o.ctx_), id_(o.id_), len_(o.len_) { o.id_ = 0; }
+    Srs(Srs&& o) noexcept : ctx_(o.ctx_), id_(o.id_), len_(o.len_), g2_(o.g2_), g2s_(o.g2s_), has_g2_(o.has_g2_) { o.id_ = 0; }
     Srs(const Srs&) = delete;
     ~Srs() {
         if (id_) typlonk_srs_free(ctx_->raw(), id_);
@@ -242,6 +265,8 @@ class Srs {
     const Context* ctx_;
     uint32_t id_ = 0;
     size_t len_ = 0;
+    pairing::G2Affine g2_{}, g2s_{};
+    bool has_g2_ = false;
 };
 
 struct KzgCommitment {
@@ -267,6 +292,9 @@ class KzgScheme {
         return KzgOpening{evaluate_in_s(q), y};
     }
     KzgCommitment identity() const { return commit(Poly::from_coefficients_vec({Fr(1)})); }
+    // kzg/src/lib.rs:66-81: pairing(W, [s]G2 - z G2) == pairing(C - y G1, G2), as e(W, A) * e(-(C - y G1), G2) == 1
+    bool verify(const KzgCommitment& commitment, const KzgOpening& opening, const Fr& z) const;
+    const Srs& srs() const { return srs_; }
 
    private:
     // kzg/src/lib.rs:41-54: assert!(srs.len() > degree) then sum coeff_i * srs_i -> the MSM
@@ -299,6 +327,33 @@ inline G1Point g1_mul(const Context& ctx, const G1Point& p, const Fr& k) {
     return KzgScheme(one).commit(Poly::from_coefficients_vec({k})).p;
 }
 inline G1Point g1_neg(const Context& ctx, const G1Point& p) { return g1_mul(ctx, p, -Fr::one()); }
+// sum_i k_i P_i: one small MSM over an SRS made of the points (the verifier's linear combinations of commitments)
+inline G1Point g1_lincomb(const Context& ctx, const std::vector<G1Point>& pts, const std::vector<Fr>& ks) {
+    Srs bases = Srs::from_points(ctx, pts);
+    std::vector<Fr> c = ks;
+    G1Point out;
+    uint8_t inf = 0;
+    check(typlonk_msm_g1(ctx.raw(), bases.id(), c[0].limbs(), c.size(), out.xy, &inf), ctx.raw());
+    out.infinity = inf != 0;
+    return out;
+}
+inline pairing::G1Aff to_pairing(const G1Point& p, bool negate = false) {
+    pairing::G1Aff a;
+    std::memcpy(a.x.v, p.xy, 48);
+    std::memcpy(a.y.v, p.xy + 6, 48);
+    if (negate) a.y = ty::fe_neg(a.y);
+    a.infinity = p.infinity;
+    return a;
+}
+inline bool KzgScheme::verify(const KzgCommitment& commitment, const KzgOpening& opening, const Fr& z) const {
+    const Context& ctx = srs_.ctx();
+    const pairing::G2Affine a = pairing::g2_add(srs_.g2s(), pairing::g2_neg(pairing::g2_mul(srs_.g2(), z.v)));
+    const G1Point g = srs_.g1_ref()[0];
+    const G1Point b = g1_lincomb(ctx, {commitment.p, g}, {Fr::one(), -opening.y});  // C - y G1
+    const pairing::G1Aff ps[2] = {to_pairing(opening.p), to_pairing(b, /*negate=*/true)};
+    const pairing::G2Affine qs[2] = {a, srs_.g2()};
+    return pairing::pairing_product_is_one(ps, qs, 2);
+}
 
 }  // namespace kzg
 
@@ -361,6 +416,15 @@ class CompiledCircuit {
                 g.infinity = inf[k] != 0;
                 (k < 5 ? fixed_commitments[k] : sigma_commitments[k - 5]) = kzg::KzgCommitment{g};
             }
+        }
+        for (int i = 0; i < 3; ++i) {  // the verifier evaluates the sigma polynomials at zeta (sigma_evals)
+            std::vector<Fr> co(n_);
+            const int rc = typlonk_buf_download(c, polys[5 + i], 0, co[0].limbs(), n_);
+            if (rc < 0) {
+                for (typlonk_buf* b : polys) typlonk_buf_free(c, b);
+                check(rc, c);
+            }
+            sigma_polys_[i] = poly::DensePolynomial::from_coefficients_vec(std::move(co));
         }
         const typlonk_buf* sel[5] = {polys[0], polys[1], polys[2], polys[3], polys[4]};
         const typlonk_buf* sig[3] = {polys[5], polys[6], polys[7]};
@@ -435,6 +499,64 @@ class CompiledCircuit {
         return p;
     }
 
+    // plonk::proof::verify (proof.rs:195-235): recompute the challenges from the commitments (verify_challenges,
+    // :236-246), check the five openings (verify_openings, :247-272), rebuild the linearisation commitment (:441-503)
+    // and check its opening, which must evaluate to zero.  `public_inputs` as for prove().
+    bool verify(const Proof& proof, const std::vector<Fr>& public_inputs = {}) const {
+        const Context& ctx = srs_.ctx();
+        const kzg::KzgScheme scheme(srs_);
+        // verify_challenges
+        uint64_t xy[4][12];
+        uint8_t inf[4];
+        const kzg::G1Point* cm[4] = {&proof.a_commit.p, &proof.b_commit.p, &proof.c_commit.p, &proof.permutation.commitment.p};
+        for (int i = 0; i < 4; ++i) {
+            std::memcpy(xy[i], cm[i]->xy, 96);
+            inf[i] = cm[i]->infinity;
+        }
+        uint64_t ch[8];
+        Fr beta, gamma, alpha, point;
+        check(typlonk_transcript_challenges(&xy[0][0], inf, 3, 2, ch));
+        std::memcpy(beta.v.v, ch, 32);
+        std::memcpy(gamma.v.v, ch + 4, 32);
+        check(typlonk_transcript_challenges(&xy[0][0], inf, 4, 2, ch));
+        std::memcpy(alpha.v.v, ch, 32);
+        std::memcpy(point.v.v, ch + 4, 32);
+        if (proof.evaluation_point != point) return false;  // :212-214
+        const poly::Radix2EvaluationDomain domain(ctx, n_);
+        Fr public_eval = Fr::zero();
+        if (!public_inputs.empty()) public_eval = poly::interpolate(public_inputs, domain).evaluate(point);
+        // verify_openings
+        const Fr w = domain.element(1);
+        if (!scheme.verify(proof.a_commit, proof.a, point) || !scheme.verify(proof.b_commit, proof.b, point) ||
+            !scheme.verify(proof.c_commit, proof.c, point))
+            return false;
+        if (!scheme.verify(proof.permutation.commitment, proof.permutation.z, point) ||
+            !scheme.verify(proof.permutation.commitment, proof.permutation.zw, point * w))
+            return false;
+        // linearisation_commitment
+        const Fr a = proof.a.eval(), b = proof.b.eval(), c = proof.c.eval();
+        const Fr zw_eval = proof.permutation.zw.eval();
+        const Fr advice[3] = {a, b, c};
+        Fr sigma_evals[3];
+        for (int i = 0; i < 3; ++i) sigma_evals[i] = sigma_polys_[i].evaluate(point);  // permutation/src/lib.rs:165-176
+        Fr l2 = Fr::one();
+        for (int i = 0; i < 3; ++i) l2 *= advice[i] + beta * cosets_[i] * point + gamma;
+        const Fr zn = point.pow(n_);
+        const Fr vanish = zn - Fr::one();
+        Fr l0 = Fr::one();  // L0(zeta) = (zeta^n - 1) / (n (zeta - 1)); 1 at zeta = 1  (utils.rs:150-159)
+        if (point != Fr::one()) l0 = vanish * (Fr((int64_t)n_) * (point - Fr::one())).inverse();
+        Fr l3 = Fr::one();
+        for (int i = 0; i < 2; ++i) l3 *= advice[i] + beta * sigma_evals[i] + gamma;
+        const Fr constant = alpha * (l3 * (c + gamma) * zw_eval) + l0 * alpha * alpha + public_eval;
+        const std::vector<kzg::G1Point> bases = {fixed_commitments[0].p, fixed_commitments[1].p, fixed_commitments[2].p,
+                                                 fixed_commitments[3].p, fixed_commitments[4].p, proof.permutation.commitment.p,
+                                                 sigma_commitments[2].p, srs_.g1_ref()[0], proof.t[0].p, proof.t[1].p, proof.t[2].p};
+        const std::vector<Fr> ks = {a, b, -c, a * b, Fr::one(), l2 * alpha + l0 * alpha * alpha,
+                                    -(l3 * alpha * beta * zw_eval), -constant, -vanish, -(vanish * zn), -(vanish * zn * zn)};
+        const kzg::KzgCommitment r{kzg::g1_lincomb(ctx, bases, ks)};
+        return scheme.verify(r, proof.r, point) && proof.r.eval().is_zero();
+    }
+
    private:
     typlonk_buf* upload(const std::vector<Fr>& v) const {
         typlonk_ctx* c = srs_.ctx().raw();
@@ -457,6 +579,7 @@ class CompiledCircuit {
     size_t n_;
     Fr cosets_[3];
     uint32_t circuit_ = 0;
+    poly::DensePolynomial sigma_polys_[3];
 };
 
 }  // namespace plonk
