@@ -49,6 +49,50 @@ def test_host_pairing_properties_and_equality_with_the_python_statement(built):
     assert got == PR.pairing(O.G1, PR.G2)
 
 
+def _cycles(perm):
+    seen, out = set(), set()
+    for s in range(len(perm)):
+        if s in seen:
+            continue
+        cyc, k = [], s
+        while k not in seen:
+            seen.add(k)
+            cyc.append(k)
+            k = perm[k]
+        out.add(frozenset(cyc))
+    return out
+
+
+def test_front_end_tables_equal_the_hand_laid_oracle_tables(built):
+    """circuit_host.hpp: the recording run of the README circuit (CircuitDescription -> gates, copy constraints, sigma)
+    against the tables oracle/plonk_oracle.py writes down by hand for the same circuit; the cycle ORDER is free (the
+    reference iterates a HashMap), the partition and the selector rows are not"""
+    from oracle import plonk_oracle as PO
+
+    out = _run("test_circuit_tables_host")
+    for t in ("permutation ok", "tables ok", "witness ok"):
+        assert t in out
+    lines = {l.split("=")[0]: l.split("=")[1] for l in out.splitlines() if "=" in l and not l.startswith("circuit2")}
+    log_n, cols, q, perm = PO.pythagorean_circuit([3, 4, 5])
+    n = 1 << log_n
+    for k, name in enumerate(("q_l", "q_r", "q_o", "q_m", "q_c")):
+        assert [int(x, 16) for x in lines[f"q{k}"].split(",")] == q[name]
+    got_perm = [int(x) for x in lines["perm"].split(",")]
+    assert _cycles(got_perm) == _cycles(perm)
+    _, sig = PO.compile_permutation(got_perm, n, log_n)
+    for i in range(3):
+        assert [int(x, 16) for x in lines[f"sigma{i}"].split(",")] == sig[i]
+
+
+@pytest.mark.gpu
+def test_reference_circuit_tests_through_the_cpp_front_end(built):
+    """plonk/src/builder/test.rs (circuit2_test, circuit2_test_bad_inputs, circuit1_test) written against the C++ mirror:
+    build() -> prove() -> verify() with real pairings, the wrong witness refused, a 1000-gate loop circuit"""
+    out = _run("test_circuit_host")
+    for t in ("circuit2 ok", "circuit1 ok", "chain ok"):
+        assert t in out
+
+
 def test_poly_glue_under_address_and_ub_sanitizers(built, tmp_path):
     """the host-side C++ (typlonk_host.hpp + the shared field headers) compiled with ASan + UBSan on the CPU build
     (GPU sanitizers are not available on this pool): no report, same answers"""

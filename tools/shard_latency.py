@@ -1,0 +1,60 @@
+"""Where the time of one rank of an 8-way sharded 2^20 MSM goes (run on one GPU as rank r of WORLD).
+
+Prints wall time per local MSM, the kernel stage times, and the cost of the exchange path (all-gather + fold) measured
+with a one-rank RCCL group (TYPLONK_FORCE_COLLECTIVE-style), which has the launch and copy latencies of the real thing
+but no wire time."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+import typlonk_amd
+from typlonk_amd.dist import ShardedMsm, allgather_fold, local_range
+from bench import synthetic_scalars, fr_mont_limbs
+
+log_n = int(os.environ.get("LOG_N", "20"))
+world = int(os.environ.get("WORLD", "8"))
+rank = int(os.environ.get("SHARD_RANK", "0"))
+reps = int(os.environ.get("REPS", "100"))
+n = 1 << log_n
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+ctx = typlonk_amd.Context(0)
+ctx.set_profiling(True)
+sh = ShardedMsm(ctx, n + 3, rank, world, dev)
+sh.generate_srs(fr_mont_limbs(2))
+if (sh.hi - sh.lo) >= (1 << 16) and os.environ.get("TABLES", "20") != "0":
+    ctx.srs_precompute(sh.sid, int(os.environ.get("TABLES", "20")))
+full = synthetic_scalars(n, 0x5EED0000 + log_n, dev)
+for _ in range(10):
+    sh.msm_local_devptr(full.data_ptr(), n)
+stages = {}
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    xy, inf = sh.msm_local_devptr(full.data_ptr(), n)
+    for k, v in ctx.profile():
+        stages[k] = stages.get(k, 0.0) + v
+wall = (time.perf_counter() - t0) / reps * 1e3
+out = {"log_n": log_n, "world": world, "rank": rank, "local_terms": local_range(n, n + 3, world, rank)[1] - local_range(n, n + 3, world, rank)[0],
+       "local_msm_wall_ms": round(wall, 4), "stages_ms": {k: round(v / reps, 4) for k, v in stages.items()}}
+ctx.set_profiling(False)
+for _ in range(10):
+    sh.msm_local_devptr(full.data_ptr(), n)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    xy, inf = sh.msm_local_devptr(full.data_ptr(), n)
+out["local_msm_wall_noprof_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+for _ in range(10):
+    allgather_fold(xy, inf, dev)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    allgather_fold(xy, inf, dev)
+out["exchange_fold_ms_one_rank_group"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+print(json.dumps(out))
+dist.destroy_process_group()

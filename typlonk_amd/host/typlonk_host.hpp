@@ -128,6 +128,17 @@ struct DensePolynomial {
     }
 };
 
+// Fr::get_root_of_unity(2^log_size): TWO_ADIC_ROOT_OF_UNITY = 7^((r-1)/2^32), squared (32 - log_size) times
+inline Fr two_adic_root(uint32_t log_size) {
+    if (log_size > 32) check(TYPLONK_ERR_DOMAIN);
+    ty::Fr c;
+    const uint32_t root[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u, 0x22c813b4u, 0xd09b6819u, 0xdfe81f20u, 0x16a2a19eu};
+    for (int i = 0; i < 8; ++i) c.v[i] = root[i];
+    Fr w(ty::fe_to_mont(c));
+    for (uint32_t i = log_size; i < 32; ++i) w = w * w;
+    return w;
+}
+
 // ark-poly 0.3.0 Radix2EvaluationDomain<Fr> (what GeneralEvaluationDomain::new returns for BLS12-381 Fr)
 class Radix2EvaluationDomain {
    public:
@@ -139,13 +150,7 @@ class Radix2EvaluationDomain {
             if (++log_size_ > 32) check(TYPLONK_ERR_DOMAIN);
         }
         size_ = 1ull << log_size_;
-        // TWO_ADIC_ROOT_OF_UNITY = 7^((r-1)/2^32), squared (32 - log_size) times
-        ty::Fr c;
-        const uint32_t root[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u,
-                                  0x22c813b4u, 0xd09b6819u, 0xdfe81f20u, 0x16a2a19eu};
-        for (int i = 0; i < 8; ++i) c.v[i] = root[i];
-        Fr w(ty::fe_to_mont(c));
-        for (uint32_t i = log_size_; i < 32; ++i) w = w * w;
+        const Fr w = two_adic_root(log_size_);
         group_gen = w;
         group_gen_inv = w.inverse();
         size_inv = Fr((int64_t)size_).inverse();
@@ -257,6 +262,13 @@ class Srs {
         }
         return out;
     }
+    G1Point g1_generator() const {  // g1_ref()[0] without the other len - 1 points
+        G1Point g;
+        uint8_t inf = 0;
+        check(typlonk_srs_download(ctx_->raw(), id_, 0, 1, g.xy, &inf), ctx_->raw());
+        g.infinity = inf != 0;
+        return g;
+    }
     uint32_t id() const { return id_; }
     const Context& ctx() const { return *ctx_; }
 
@@ -348,7 +360,7 @@ inline pairing::G1Aff to_pairing(const G1Point& p, bool negate = false) {
 inline bool KzgScheme::verify(const KzgCommitment& commitment, const KzgOpening& opening, const Fr& z) const {
     const Context& ctx = srs_.ctx();
     const pairing::G2Affine a = pairing::g2_add(srs_.g2s(), pairing::g2_neg(pairing::g2_mul(srs_.g2(), z.v)));
-    const G1Point g = srs_.g1_ref()[0];
+    const G1Point g = srs_.g1_generator();
     const G1Point b = g1_lincomb(ctx, {commitment.p, g}, {Fr::one(), -opening.y});  // C - y G1
     const pairing::G1Aff ps[2] = {to_pairing(opening.p), to_pairing(b, /*negate=*/true)};
     const pairing::G2Affine qs[2] = {a, srs_.g2()};
@@ -372,12 +384,13 @@ struct Proof {
     kzg::KzgCommitment t[3];          // quotient slices
     kzg::KzgOpening r;                // linearisation polynomial at zeta: r.eval() == 0 for a valid proof
     Fr beta, gamma, alpha;            // the challenges used (the reference's verifier recomputes them, :236-246)
+    std::vector<Fr> public_inputs;    // padded column (filled by plonk::Circuit::prove; the verifier reads it, :205-210)
 };
 
 // The prover-relevant part of plonk::CompiledCircuit (/root/reference/plonk/src/lib.rs:19-35): the SRS, the domain,
 // the five selector polynomials (gate_constrains, builder.rs:76-90) and the sigma columns with their cosets
-// (copy_constrains, permutation/src/lib.rs:141-154).  The tables come from the reference's front end
-// (CircuitDescription::build, out of scope here) as EVALUATIONS over the domain, exactly as builder.rs:85 interpolates
+// (copy_constrains, permutation/src/lib.rs:141-154).  The tables come from the front end
+// (CircuitDescription::build; circuit_host.hpp) as EVALUATIONS over the domain, exactly as builder.rs:85 interpolates
 // them; they are interpolated on the device once and cached for every later proof (typlonk_circuit_load).
 class CompiledCircuit {
    public:
@@ -550,7 +563,7 @@ class CompiledCircuit {
         const Fr constant = alpha * (l3 * (c + gamma) * zw_eval) + l0 * alpha * alpha + public_eval;
         const std::vector<kzg::G1Point> bases = {fixed_commitments[0].p, fixed_commitments[1].p, fixed_commitments[2].p,
                                                  fixed_commitments[3].p, fixed_commitments[4].p, proof.permutation.commitment.p,
-                                                 sigma_commitments[2].p, srs_.g1_ref()[0], proof.t[0].p, proof.t[1].p, proof.t[2].p};
+                                                 sigma_commitments[2].p, srs_.g1_generator(), proof.t[0].p, proof.t[1].p, proof.t[2].p};
         const std::vector<Fr> ks = {a, b, -c, a * b, Fr::one(), l2 * alpha + l0 * alpha * alpha,
                                     -(l3 * alpha * beta * zw_eval), -constant, -vanish, -(vanish * zn), -(vanish * zn * zn)};
         const kzg::KzgCommitment r{kzg::g1_lincomb(ctx, bases, ks)};
