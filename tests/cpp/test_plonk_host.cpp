@@ -123,6 +123,41 @@ int main() {
         REQUIRE(!circuit.verify(t));
     }
     std::printf("verify ok\n");
+    // ---- public inputs: every gate row reads q_l a + q_r b + q_m a b + q_c - q_o c + PI_j = 0 (proof.rs:317-320) ----
+    {
+        std::vector<Fr> pi(n);
+        pi[0] = Fr(5);
+        pi[7] = Fr(-3);
+        pi[gates - 1] = Fr(1234567);
+        std::vector<Fr> adv[3];
+        Fr y(3);
+        for (size_t j = 0; j < gates; ++j) {
+            adv[0].push_back(y);
+            adv[1].push_back(y);
+            y = y * y + pi[j];
+            adv[2].push_back(y);
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 3; ++k) adv[i].push_back(Fr(77 + 3 * i + k));
+        const plonk::Proof pp = circuit.prove(adv, pi);          // r(zeta) == 0 or this throws
+        REQUIRE(pp.r.eval().is_zero());
+        REQUIRE(poly::interpolate(pi, domain).evaluate(pp.evaluation_point) != Fr::zero());
+        // the witness does not satisfy the circuit WITHOUT the public inputs
+        bool refused = false;
+        try {
+            (void)circuit.prove(adv);
+        } catch (const std::runtime_error&) {
+            refused = true;
+        }
+        REQUIRE(refused);
+        // the reference's verifier has the sign of PI(zeta) the other way round than its prover (proof.rs:402 against
+        // :497-502) and rejects this honest proof; with the prover's sign everything else of the verifier accepts it
+        using Sign = plonk::CompiledCircuit::PublicInputSign;
+        REQUIRE(!circuit.verify(pp, pi));
+        REQUIRE(circuit.verify(pp, pi, Sign::AsProver));
+        REQUIRE(!circuit.verify(pp, {}, Sign::AsProver));        // and the public inputs are bound
+        std::printf("public inputs ok\n");
+    }
     // same witness, same proof (deterministic transcript)
     const plonk::Proof again = circuit.prove(advice);
     REQUIRE(again.permutation.commitment == proof.permutation.commitment && again.t[2] == proof.t[2] && again.r.p == proof.r.p);

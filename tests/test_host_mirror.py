@@ -32,7 +32,7 @@ def test_prove_through_the_cpp_mirror(built):
     """plonk::CompiledCircuit::prove (typlonk_host.hpp -> typlonk_prove): squaring chain built in C++, r(zeta) == 0, every
     opening in its trapdoor form, a wrong witness throws"""
     out = _run("test_plonk_host")
-    for t in ("prove ok", "openings ok", "commitments ok", "verify ok", "bad witness rejected ok"):
+    for t in ("prove ok", "openings ok", "commitments ok", "verify ok", "public inputs ok", "bad witness rejected ok"):
         assert t in out
 
 

@@ -515,7 +515,13 @@ class CompiledCircuit {
     // plonk::proof::verify (proof.rs:195-235): recompute the challenges from the commitments (verify_challenges,
     // :236-246), check the five openings (verify_openings, :247-272), rebuild the linearisation commitment (:441-503)
     // and check its opening, which must evaluate to zero.  `public_inputs` as for prove().
-    bool verify(const Proof& proof, const std::vector<Fr>& public_inputs = {}) const {
+    //
+    // Public inputs: the reference's prover ADDS PI(zeta) to r (proof.rs:401-402) and its verifier adds public_eval to the
+    // constant it SUBTRACTS (:497-502), so with PI(zeta) != 0 the reference rejects its own honest proofs (its tests only
+    // use vec![0]).  The default follows the reference; PublicInputSign::AsProver is the consistent verifier.
+    enum class PublicInputSign { AsReference, AsProver };
+    bool verify(const Proof& proof, const std::vector<Fr>& public_inputs = {},
+                PublicInputSign pi_sign = PublicInputSign::AsReference) const {
         const Context& ctx = srs_.ctx();
         const kzg::KzgScheme scheme(srs_);
         // verify_challenges
@@ -560,7 +566,8 @@ class CompiledCircuit {
         if (point != Fr::one()) l0 = vanish * (Fr((int64_t)n_) * (point - Fr::one())).inverse();
         Fr l3 = Fr::one();
         for (int i = 0; i < 2; ++i) l3 *= advice[i] + beta * sigma_evals[i] + gamma;
-        const Fr constant = alpha * (l3 * (c + gamma) * zw_eval) + l0 * alpha * alpha + public_eval;
+        const Fr constant = alpha * (l3 * (c + gamma) * zw_eval) + l0 * alpha * alpha +
+                            (pi_sign == PublicInputSign::AsReference ? public_eval : -public_eval);
         const std::vector<kzg::G1Point> bases = {fixed_commitments[0].p, fixed_commitments[1].p, fixed_commitments[2].p,
                                                  fixed_commitments[3].p, fixed_commitments[4].p, proof.permutation.commitment.p,
                                                  sigma_commitments[2].p, srs_.g1_generator(), proof.t[0].p, proof.t[1].p, proof.t[2].p};
