@@ -45,8 +45,46 @@ struct Chain1000 : plonk::CircuitDescription<2, Chain1000> {  // y == x^(2^500) 
     }
 };
 
-int main() {
+struct SquaringChain20 : plonk::CircuitDescription<1, SquaringChain20> {  // 2^20 - 3 gates: BASELINE config 3's size
+    template <class V>
+    static void run(std::array<V, 1> in) {
+        V x = in[0];
+        for (int i = 0; i < (1 << 20) - 3; ++i) x = x.clone() * x;
+    }
+};
+
+#include <chrono>
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// `test_circuit_host big`: the 2^20-row circuit through the same front end -- build, prove twice, verify
+static int big(const Context& ctx) {
+    double t0 = now_ms();
+    auto circuit = SquaringChain20::build(ctx);
+    const double t_build = now_ms() - t0;
+    REQUIRE(circuit.rows == (size_t)1 << 20);
+    t0 = now_ms();
+    auto proof = circuit.prove({3}, {0});
+    const double t_first = now_ms() - t0;
+    t0 = now_ms();
+    proof = circuit.prove({5}, {0});
+    const double t_prove = now_ms() - t0;
+    t0 = now_ms();
+    REQUIRE(circuit.verify(proof));
+    const double t_verify = now_ms() - t0;
+    plonk::Proof t = proof;
+    t.permutation.zw.y = t.permutation.zw.y + Fr::one();
+    REQUIRE(!circuit.verify(t));
+    std::printf("big: rows=%zu build_ms=%.0f first_prove_ms=%.0f prove_ms=%.0f verify_ms=%.0f\n", circuit.rows, t_build, t_first,
+                t_prove, t_verify);
+    std::printf("all ok\n");
+    return 0;
+}
+
+int main(int argc, char** argv) {
     Context ctx(0);
+    if (argc > 1 && std::string(argv[1]) == "big") return big(ctx);
     {   // circuit2_test
         auto circuit = Circuit2::build(ctx);
         REQUIRE(circuit.rows == 8);

@@ -8,9 +8,9 @@ import pytest
 from helpers import ROOT
 
 
-def _run(name):
+def _run(name, *args):
     exe = os.path.join(ROOT, "tests", "cpp", name)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("all ok"), r.stdout
     return r.stdout
@@ -91,6 +91,14 @@ def test_reference_circuit_tests_through_the_cpp_front_end(built):
     out = _run("test_circuit_host")
     for t in ("circuit2 ok", "circuit1 ok", "chain ok"):
         assert t in out
+
+
+@pytest.mark.gpu
+def test_a_2_20_row_circuit_through_the_cpp_front_end(built):
+    """BASELINE config 3's size from the caller's side: 1,048,573 squarings written as a loop over a generic variable,
+    compiled (tables, SRS, eight fixed commitments), proved on the GPU and verified with pairings, all from C++"""
+    out = _run("test_circuit_host", "big")
+    assert "rows=1048576" in out
 
 
 def test_poly_glue_under_address_and_ub_sanitizers(built, tmp_path):

@@ -377,6 +377,7 @@ class Circuit {
     Circuit() = default;
     void witness(const std::array<Fr, INPUTS>& inputs, std::vector<Fr> (&advice)[3]) const {
         auto rec = std::make_shared<Advice>();
+        for (auto& col : rec->col) col.reserve(rows);
         DESC::template run<ComputeVar>(detail::compute_inputs_impl(inputs, rec, std::make_index_sequence<INPUTS>{}));
         for (int i = 0; i < 3; ++i) {
             advice[i] = std::move(rec->col[i]);
