@@ -174,6 +174,11 @@ int main() {
         REQUIRE(rec->col[0].size() == 4);
         REQUIRE(rec->col[0][3] == Fr(9) && rec->col[1][3] == Fr(16) && rec->col[2][3] == Fr(25) && rec->col[2][2] == Fr(36));
     }
+    {   // blinding values: distinct draws, every one a canonical residue (round trip through the integer form)
+        const Fr x = plonk::random_fr(), y = plonk::random_fr();
+        REQUIRE(x != y);
+        REQUIRE(Fr(ty::fe_to_mont(ty::fe_from_mont(x.v))) == x);
+    }
     std::printf("witness ok\n");
     std::printf("all ok\n");
     return 0;

@@ -85,6 +85,12 @@ struct StdRng {
     uint64_t counter = 0;
     uint32_t buf[16];
     int have = 0;  // words left in buf
+    // keyed directly with 256 bits (rand's thread_rng is this generator seeded from the operating system)
+    static StdRng from_key(const uint32_t k[8]) {
+        StdRng r(0);
+        for (int i = 0; i < 8; ++i) r.key[i] = k[i];
+        return r;
+    }
     explicit StdRng(uint64_t state) {
         for (int i = 0; i < 8; ++i) {
             state = state * 6364136223846793005ull + 11634580027462260723ull;

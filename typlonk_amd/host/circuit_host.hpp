@@ -33,30 +33,25 @@
 #include <unordered_map>
 #include <utility>
 
+#include "../csrc/transcript.hpp"
 #include "typlonk_host.hpp"
 
 namespace typlonk {
 namespace plonk {
 
-// Fr::rand with the thread's generator (proof.rs:42-46, srs.rs:36-40): uniform below r
+// Fr::rand(&mut rand::thread_rng()) (proof.rs:42-46, srs.rs:36-40): blinding rows and the SRS secret need a
+// cryptographic generator -- the library's ChaCha12 (csrc/transcript.hpp, the same StdRng the transcript uses), keyed per
+// thread with 256 bits from the operating system
 inline Fr random_fr() {
-    static thread_local std::mt19937_64 gen{std::random_device{}()};
-    static const uint64_t R[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
-    for (;;) {
-        uint64_t l[4];
-        for (auto& x : l) x = gen();
-        l[3] >>= 1;
-        bool below = false;
-        for (int i = 3; i >= 0; --i)
-            if (l[i] != R[i]) {
-                below = l[i] < R[i];
-                break;
-            }
-        if (!below) continue;
-        Fr f;
-        std::memcpy(f.limbs(), l, 32);
-        return f;
-    }
+    static thread_local ty::StdRng rng = [] {
+        std::random_device os;
+        uint32_t key[8];
+        for (auto& k : key) k = os();
+        return ty::StdRng::from_key(key);
+    }();
+    Fr f;
+    ty::fr_rand(rng, f.limbs());
+    return f;
 }
 
 // ---- permutation argument: cells, copy constraints, sigma ------------------------------------------------------------
