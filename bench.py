@@ -415,12 +415,22 @@ def main() -> None:
         if not ok:
             result["value"] = None
             result["error"] = "sharded GPU result differs from the oracle: number withheld"
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    # everything that can still print (RCCL reports its library path when a communicator comes up or goes away) happens
+    # before the contract line, so that the JSON is the last line of rank 0's output
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    # librccl prints through C stdio, which is block-buffered when stdout is a pipe or a file and would otherwise be
+    # flushed at exit, after Python's own line
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    sys.stderr.flush()
+    if rank == 0:
+        if world > 1:
+            time.sleep(0.5)  # the other ranks share this stdout: let their last lines land first
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
