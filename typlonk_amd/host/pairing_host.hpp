@@ -11,8 +11,8 @@
 // obviously the definition over speed (affine line steps, one square-and-multiply final exponentiation per CHECK -- a
 // KZG verification is e(W, A) * e(-B, G2) == 1, i.e. two Miller loops and one exponentiation, ~0.15 s).  An accept /
 // reject decision does not depend on the normalisation of e.  Pinned by what a pairing must satisfy (bilinearity,
-// non-degeneracy, order r) and against the independent Python statement in oracle/pairing.py (tests/cpp/test_pairing_host.cpp,
-// tests/test_host_mirror.py).  Field elements are arkworks residues (Montgomery, R = 2^384): the C-ABI form.
+// non-degeneracy, order r) and, in the tests only, against the Python big-integer statement the test infrastructure keeps
+// (tests/cpp/test_pairing_host.cpp, tests/test_host_mirror.py).  Field elements are arkworks residues (Montgomery, R = 2^384): the C-ABI form.
 #pragma once
 #include <array>
 #include <cstdint>
