@@ -364,6 +364,18 @@ def main() -> None:
                 "kind": "port (bucket method, not the reference's algorithm)", "cores": f_thr, "window_bits": cf,
                 "sample": f"first {mf} terms", "seconds": tf, "terms_per_s": mf / tf, "value": f_ops / tf,
                 "unit": "G1-adds/s", "ntt_ms_1_thread": tn * 1e3, "ntt_log_n": mf.bit_length() - 1}
+            # the north-star's ">= 10x prove() over the CPU reference": prove()'s 13 MSMs alone (proof.rs call sites, SURVEY
+            # 8a7) at the two measured CPU rates -- a LOWER bound of the CPU time (its NTTs, and the reference's schoolbook
+            # quotient of ~19 n^2 multiplications, are not counted)
+            if "prove_ms" in result:
+                msm_terms = 13 * n
+                result["prove_vs_cpu"] = {
+                    "gpu_prove_ms": result["prove_ms"],
+                    "cpu_reference_path_13_msms_s": msm_terms / (ms / tc), "cpu_reference_cores": 1,
+                    "cpu_all_cores_bucket_method_13_msms_s": msm_terms / (mf / tf), "cpu_all_cores": f_thr,
+                    "speedup_vs_reference_path": msm_terms / (ms / tc) / (result["prove_ms"] * 1e-3),
+                    "speedup_vs_all_cores": msm_terms / (mf / tf) / (result["prove_ms"] * 1e-3),
+                    "note": "CPU side = MSMs only, extrapolated from the timed samples; a lower bound of the CPU prove()"}
             if not (parity_sample and parity_full and parity_fair):
                 result["value"] = None
                 result["error"] = "GPU result differs from the oracle: number withheld"
