@@ -101,13 +101,14 @@ def test_a_2_20_row_circuit_through_the_cpp_front_end(built):
     assert "rows=1048576" in out
 
 
-def test_poly_glue_under_address_and_ub_sanitizers(built, tmp_path):
-    """the host-side C++ (typlonk_host.hpp + the shared field headers) compiled with ASan + UBSan on the CPU build
-    (GPU sanitizers are not available on this pool): no report, same answers"""
-    exe = str(tmp_path / "test_poly_host_san")
+@pytest.mark.parametrize("name", ["test_poly_host", "test_circuit_tables_host"])
+def test_host_mirror_under_address_and_ub_sanitizers(built, tmp_path, name):
+    """the host-side C++ (typlonk_host.hpp, circuit_host.hpp + the shared field headers) compiled with ASan + UBSan on the
+    CPU build (GPU sanitizers are not available on this pool): no report, same answers"""
+    exe = str(tmp_path / (name + "_san"))
     lib = os.path.join(ROOT, "typlonk_amd")
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-           os.path.join(ROOT, "tests", "cpp", "test_poly_host.cpp"), "-o", exe, "-L", lib, "-ltyplonk_hip", "-Wl,-rpath," + lib]
+           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe, "-L", lib, "-ltyplonk_hip", "-Wl,-rpath," + lib]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
