@@ -138,6 +138,8 @@ struct typlonk_ctx {
     int prover_rounds_active = 0;  // > 0 while a typlonk_prover_round* call is running (ProverRound)
     bool ntt_big_tiles = true;     // TYPLONK_NTT_BIG=0: always 1024-element tiles (three passes at 2^20)
     bool ntt_full_tables = true;   // TYPLONK_NTT_FULL_TABLES=0: compose twiddles / coset powers from two-level tables
+    int ntt_fr30 = 1;              // TYPLONK_NTT_FR30: 0 = off, 1 = 9 x 30-bit butterflies (fr30.hpp) up to 2^19,
+                                   // 2 = for every transform (the 4096-element tiles of 2^20 are then not used)
     uint32_t ntt_full_max_log = 24;
     bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
     bool msm_tree_reduce = false;  // TYPLONK_MSM_REDUCE=running: running-sum + small-multiple reduction (first version)
@@ -270,6 +272,25 @@ Fr fr_domain_root(uint32_t log_n) {
     Fr w = fr_root_of_unity_2_32();
     for (uint32_t i = log_n; i < 32; ++i) w = fe_sqr(w);
     return w;
+}
+// its inverse (group_gen_inv) from the inverse of the 2^32-th root: squarings instead of a field inversion per call
+Fr fr_domain_root_inv(uint32_t log_n) {
+    Fr c;
+    const uint32_t limbs[8] = {0x3cf19a78u, 0x0fb4d6e1u, 0xb566f833u, 0x6f67d4a2u, 0xa35d0168u, 0xed4f2f74u, 0x6e19c653u, 0x0538a6f6u};
+    for (int i = 0; i < 8; ++i) c.v[i] = limbs[i];
+    Fr w = fe_to_mont(c);
+    for (uint32_t i = log_n; i < 32; ++i) w = fe_sqr(w);
+    return w;
+}
+// (2^log_n)^-1 = ((r + 1) / 2)^log_n  (size_inv)
+Fr fr_inv_pow2(uint32_t log_n) {
+    Fr c;
+    const uint32_t limbs[8] = {0x80000001u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};
+    for (int i = 0; i < 8; ++i) c.v[i] = limbs[i];
+    const Fr half = fe_to_mont(c);
+    Fr x = Fr::one();
+    for (uint32_t i = 0; i < log_n; ++i) x = fe_mul(x, half);
+    return x;
 }
 
 Fr fr_from_u64(uint64_t x) {
@@ -434,7 +455,8 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     uint32_t ks[4], P;
     // (not inside a prover round: there the 144 KiB workgroups crowd out the LDS of the MSM lanes' sort kernels running
     // beside them -- prove() 38.1 -> 38.3 ms in the same-box A/B)
-    const bool big = ctx->ntt_big_tiles && log_n == 20 && ctx->prover_rounds_active == 0;
+    bool big = ctx->ntt_big_tiles && log_n == 20 && ctx->prover_rounds_active == 0;
+    if (big && ctx->ntt_fr30 == 2 && ctx->ntt_full_tables) big = false;  // 36 B per element: 4096 of them do not fit
     const uint32_t cap = big ? 12 : 10;        // log2 of the tile capacity
     const unsigned threads = big ? 1024 : 256;
     split_log(log_n, ks, &P, big);
@@ -447,11 +469,16 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         scratch = (Fr*)ctx->ntt_scratch.p;
     }
 
-    // coset / scaling tables
+    // measured: the 9 x 30-bit kernel is 9-12 % faster up to 2^19; at 2^20 the two-pass 4096-element
+    // tiles of the 8 x 32 kernel win, and from 2^21 on the 36-B LDS elements cost a workgroup per CU (3 instead of 4)
+    // and a forward transform pays one extra reducing multiplication per element: mode 1 (default) stops at 2^19
+    const bool want30 = ctx->ntt_fr30 != 0 && ctx->ntt_full_tables && !big && (ctx->ntt_fr30 == 2 || log_n <= 19);
+
+    // coset / scaling tables (the full tables of the 8 x 32 kernel are not built when the other kernel will run)
     Table pre_lo{}, pre_hi{}, post_lo{}, post_hi{}, scale{}, pre_full{}, post_full{};
     uint32_t pre_h = 0, post_h = 0;
     Fr n_inv = Fr::one();
-    if (inverse) n_inv = fe_inv(fr_from_u64(N));
+    if (inverse) n_inv = fr_inv_pow2(log_n);
     if (coset_shift) {
         Fr g;
         memcpy(g.v, coset_shift, sizeof(g.v));
@@ -461,19 +488,68 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             if (rc) return rc;
             rc = get_pow2l(ctx, key, g, Fr::one(), log_n, &pre_lo, &pre_hi, &pre_h);
             if (rc) return rc;
-            if ((rc = get_full_table(ctx, key + ":full", pre_lo, pre_hi, pre_h, 0, N, &pre_full))) return rc;
+            if (!want30 && (rc = get_full_table(ctx, key + ":full", pre_lo, pre_hi, pre_h, 0, N, &pre_full))) return rc;
         } else {
-            Fr gi = fe_inv(g);
             const std::string key = "cs:i:" + std::to_string(log_n) + ":" + fr_hex(g);
+            const bool resident = ctx->tables.count(key + ":lo") && ctx->tables.count(key + ":hi");
+            const Fr gi = resident ? Fr::one() : fe_inv(g);  // only a table build needs the value
             int rc = evict_coset_tables(ctx, key, (size_t)N * sizeof(Fr));
             if (rc) return rc;
             rc = get_pow2l(ctx, key, gi, n_inv, log_n, &post_lo, &post_hi, &post_h);
             if (rc) return rc;
-            if ((rc = get_full_table(ctx, key + ":full", post_lo, post_hi, post_h, 0, N, &post_full))) return rc;
+            if (!want30 && (rc = get_full_table(ctx, key + ":full", post_lo, post_hi, post_h, 0, N, &post_full))) return rc;
         }
     } else if (inverse) {
         int rc = get_pow_table(ctx, "ninv:" + std::to_string(log_n), Fr::one(), n_inv, 1, &scale);
         if (rc) return rc;
+    }
+
+    // The 9 x 30-bit kernel (fr30.hpp) multiplies with R' = 2^270: its tables carry an extra factor 2^14 and every one
+    // of them must exist as a full table; if one cannot be built (size, memory) the transform runs on the 8 x 32 kernel.
+    Table sub30[4]{}, tw30[4]{}, pre30{}, post30{}, scale30{};
+    bool f30 = want30;
+    if (f30) {
+        const Fr c14 = fr_from_u64(1u << 14);
+        int rc = TYPLONK_OK;
+        if (coset_shift) {
+            Fr g;
+            memcpy(g.v, coset_shift, sizeof(g.v));
+            const std::string key = std::string("cs:") + (inverse ? "i:" : "f:") + std::to_string(log_n) + ":" + fr_hex(g) + ":30";
+            Table lo, hi;
+            uint32_t h = 0;
+            if (!inverse) {
+                if ((rc = get_pow2l(ctx, key, g, c14, log_n, &lo, &hi, &h))) return rc;
+                if ((rc = get_full_table(ctx, key + ":full", lo, hi, h, 0, N, &pre30))) return rc;
+                f30 = pre30.d != nullptr;
+            } else {
+                const bool resident = ctx->tables.count(key + ":lo") && ctx->tables.count(key + ":hi");
+                if ((rc = get_pow2l(ctx, key, resident ? Fr::one() : fe_inv(g), fe_mul(n_inv, c14), log_n, &lo, &hi, &h))) return rc;
+                if ((rc = get_full_table(ctx, key + ":full", lo, hi, h, 0, N, &post30))) return rc;
+                f30 = post30.d != nullptr;
+            }
+        } else if (inverse) {
+            if ((rc = get_pow_table(ctx, "ninv30:" + std::to_string(log_n), Fr::one(), fe_mul(n_inv, c14), 1, &scale30))) return rc;
+        }
+        uint64_t rl = N;
+        for (uint32_t p = 0; p < P && f30; ++p) {
+            const uint32_t k = ks[p];
+            const uint64_t M = 1ull << k;
+            const Fr w = inverse ? fr_domain_root_inv(k) : fr_domain_root(k);
+            if ((rc = get_pow_table(ctx, "sub30:" + dir + ":" + std::to_string(k), w, c14, (size_t)std::max<uint64_t>(M / 2, 1), &sub30[p])))
+                return rc;
+            if (p + 1 < P) {
+                const uint32_t lrow = ilog2_u64(rl);
+                const Fr wr = inverse ? fr_domain_root_inv(lrow) : fr_domain_root(lrow);
+                Table lo, hi;
+                uint32_t h = 0;
+                if ((rc = get_pow2l(ctx, "tw30:" + dir + ":" + std::to_string(lrow), wr, c14, lrow, &lo, &hi, &h))) return rc;
+                if ((rc = get_full_table(ctx, "tw30:" + dir + ":" + std::to_string(lrow) + ":full:" + std::to_string(k), lo, hi, h,
+                                         rl / M, rl, &tw30[p])))
+                    return rc;
+                f30 = tw30[p].d != nullptr;
+            }
+            rl /= M;
+        }
     }
 
     uint64_t row_len = N;  // length of the rows the current pass works inside
@@ -489,8 +565,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         a.row_len = row_len;
         // sub-transform twiddles w_M^e
         {
-            Fr w = fr_domain_root(k);
-            if (inverse) w = fe_inv(w);
+            const Fr w = inverse ? fr_domain_root_inv(k) : fr_domain_root(k);
             Table t;
             int rc = get_pow_table(ctx, "sub:" + dir + ":" + std::to_string(k), w, Fr::one(), (size_t)std::max<uint64_t>(M / 2, 1), &t);
             if (rc) return rc;
@@ -499,17 +574,18 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         uint32_t logT;
         if (!last) {
             const uint32_t lrow = ilog2_u64(row_len);
-            Fr w = fr_domain_root(lrow);
-            if (inverse) w = fe_inv(w);
+            const Fr w = inverse ? fr_domain_root_inv(lrow) : fr_domain_root(lrow);
             Table lo, hi;
             int rc = get_pow2l(ctx, "tw:" + dir + ":" + std::to_string(lrow), w, Fr::one(), lrow, &lo, &hi, &a.tw_h);
             if (rc) return rc;
             a.tw_lo = lo.d;
             a.tw_hi = hi.d;
             Table full;
-            rc = get_full_table(ctx, "tw:" + dir + ":" + std::to_string(lrow) + ":full:" + std::to_string(k), lo, hi, a.tw_h,
-                                a.S, row_len, &full);
-            if (rc) return rc;
+            if (!f30) {
+                rc = get_full_table(ctx, "tw:" + dir + ":" + std::to_string(lrow) + ":full:" + std::to_string(k), lo, hi, a.tw_h,
+                                    a.S, row_len, &full);
+                if (rc) return rc;
+            }
             a.tw_full = full.d;
             logT = std::min<uint32_t>(cap - k, ilog2_u64(a.S));
         } else {
@@ -548,11 +624,21 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         }
         const uint64_t E = M << logT;
         const uint64_t blocks = N / E;
-        const size_t lds = (size_t)(E + std::max<uint64_t>(M / 2, 1)) * sizeof(Fr);
+        if (f30) {
+            a.sub_tw = sub30[p].d;
+            a.tw_full = tw30[p].d;
+            a.tw_lo = a.tw_hi = nullptr;
+            a.pre_lo = a.pre_hi = a.post_lo = a.post_hi = nullptr;
+            a.pre_full = p == 0 ? pre30.d : nullptr;
+            a.post_full = last ? post30.d : nullptr;
+            a.scale = last ? scale30.d : nullptr;
+        }
+        const size_t lds = (size_t)(E + std::max<uint64_t>(M / 2, 1)) * (f30 ? 36 : sizeof(Fr));
         {
             static const char* names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
             StageTimer st(ctx, names[p]);
-            launch_ntt_pass(a, (unsigned)blocks, threads, lds, ctx->stream);
+            if (f30) launch_ntt_pass30(a, (unsigned)blocks, threads, lds, ctx->stream);
+            else launch_ntt_pass(a, (unsigned)blocks, threads, lds, ctx->stream);
         }
         HIPCHK(hipGetLastError());
         rows *= M;
@@ -1046,6 +1132,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_CHUNKS")) ctx->msm_chunks = std::max(0, std::min(atoi(e), MSM_MAX_CHUNKS));
     if (const char* e = getenv("TYPLONK_NTT_BIG")) ctx->ntt_big_tiles = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_NTT_FULL_TABLES")) ctx->ntt_full_tables = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_NTT_FR30")) ctx->ntt_fr30 = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("TYPLONK_NTT_FULL_MAX_LOG")) ctx->ntt_full_max_log = (uint32_t)atoi(e);
     *out = ctx;
     return TYPLONK_OK;

@@ -67,6 +67,8 @@ void launch_eval_multi(const Fr* const* polys, uint32_t count, uint64_t m, const
 void launch_lincomb(const LincombArgs& a, hipStream_t s);
 
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);
+// the same pass on 9 x 30-bit limbs: every table in `a` is a full table in the 2^270 domain, 36 B of LDS per element
+void launch_ntt_pass30(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);
 void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n, Fr* out, hipStream_t s);
 
 void launch_convert_points(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);

@@ -14,6 +14,7 @@
 // 1024 elements (32 KiB) and the sub-transform's twiddles w_{N_p}^e are staged in LDS.
 // Inter-pass twiddles and coset powers come from two-level tables (lo[e & mask] * hi[e >> h]),
 // each <= 2^ceil(log/2) entries, so they stay in L2.
+#include "fr30.hpp"
 #include "launch.hpp"
 
 namespace ty {
@@ -143,6 +144,117 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     }
 }
 
+// ---- the same pass on 9 x 30-bit limbs (fr30.hpp) -------------------------------------------------------------------
+// Same tiling, addressing and stage order as ntt_pass_kernel.  The LDS tile holds 9 words per element; every table
+// (sub_tw, tw_full, pre_full, post_full, scale) is in the 2^270 domain and must be a full table (capi.hip selects this
+// kernel only then).  Additions are lazy (fr30.hpp states the bounds); a pass ends with a multiplication of every
+// element -- the inter-pass twiddle, the coset / scaling factor of the last pass, or 2^270 mod r when the last pass has
+// no factor -- which brings it below 2r; the last pass then subtracts r once more where needed, so that what reaches
+// the caller is the canonical residue, bit for bit what ntt_pass_kernel writes.
+__device__ __forceinline__ Fr30 lds_ld30(const uint32_t* p) {
+    Fr30 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ void lds_st30(uint32_t* p, const Fr30& r) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = r.v[i];
+}
+__global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
+    const uint32_t NTT_THREADS = blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
+    const uint32_t k = a.k, logT = a.logT;
+    const uint32_t M = 1u << k, T = 1u << logT, E = M << logT;
+    uint32_t* tile = reinterpret_cast<uint32_t*>(ntt_smem);
+    uint32_t* stw = tile + 9 * E;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t b = blockIdx.x;
+
+    for (uint32_t i = tid; i < (M >> 1); i += NTT_THREADS) lds_st30(stw + 9 * i, fr30_unpack(ntt_ld(a.sub_tw + i)));
+
+    uint64_t base = 0, c0 = 0, q = 0, k1base = 0;
+    if (!a.last) {
+        const uint64_t tiles_per_row = a.S >> logT;
+        const uint64_t row = b / tiles_per_row;
+        c0 = (b % tiles_per_row) << logT;
+        base = row * a.row_len + c0;
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t t = idx & (T - 1), i = idx >> logT;
+            const uint64_t g = base + (uint64_t)i * a.S + t;
+            Fr30 x = fr30_unpack(ntt_ld(a.in + g));
+            if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
+            lds_st30(tile + 9 * idx, x);
+        }
+    } else {
+        q = b % a.Q;
+        k1base = (b / a.Q) << logT;
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t i = idx & (M - 1), t = idx >> k;
+            const uint64_t g = ((k1base + t) * a.Q + q) * M + i;
+            Fr30 x = fr30_unpack(ntt_ld(a.in + g));
+            if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
+            lds_st30(tile + 9 * ((i << logT) + t), x);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t nb = E >> 1;
+    for (uint32_t s = 0; s < k; ++s) {
+        const uint32_t lh = k - 1 - s;
+        const uint32_t half = 1u << lh;
+        const bool split = (lh == 1) && (nb >= 2 * NTT_THREADS);
+        for (uint32_t qq = tid; qq < nb; qq += NTT_THREADS) {
+            uint32_t t, j;
+            if (split) {
+                const uint32_t sweep = qq / NTT_THREADS;
+                const uint32_t q2 = (sweep >> 1) * NTT_THREADS + tid;
+                t = q2 & (T - 1);
+                j = ((q2 >> logT) << 1) | (sweep & 1u);
+            } else {
+                t = qq & (T - 1);
+                j = qq >> logT;
+            }
+            const uint32_t pos = j & (half - 1);
+            const uint32_t i0 = ((j >> lh) << (lh + 1)) + pos;
+            uint32_t* pa = tile + 9 * ((i0 << logT) + t);
+            uint32_t* pb = tile + 9 * (((i0 + half) << logT) + t);
+            const Fr30 x = lds_ld30(pa), y = lds_ld30(pb);
+            lds_st30(pa, fr30_add(x, y));
+            const Fr30 d = fr30_sub(x, y);
+            if (lh == 0 || (split && pos == 0)) {
+                lds_st30(pb, d);  // twiddle 1
+            } else {
+                lds_st30(pb, fr30_mul(d, lds_ld30(stw + 9 * (pos << s))));
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!a.last) {
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t t = idx & (T - 1), kk = idx >> logT;
+            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
+            Fr30 x = lds_ld30(tile + 9 * ((src << logT) + t));
+            x = fr30_mul(x, fr30_unpack(ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t))));
+            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), fr30_pack(x));  // < 2r: the next pass takes it as it is
+        }
+    } else {
+        const uint64_t qrev = (q / a.N3) + a.N2 * (q % a.N3);
+        const uint64_t obase = k1base + a.N1 * qrev;
+        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+            const uint32_t t = idx & (T - 1), kk = idx >> logT;
+            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
+            Fr30 x = lds_ld30(tile + 9 * ((src << logT) + t));
+            const uint64_t o = obase + t + a.out_stride * kk;
+            if (a.post_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.post_full + o)));
+            else if (a.scale) x = fr30_mul(x, fr30_unpack(ntt_ld(a.scale)));
+            else x = fr30_mul(x, fr30_const_one());
+            ntt_st(a.out + o, fr30_to_canonical(x));
+        }
+    }
+}
+
 // out[idx] = lo/hi power at exponent (idx % S) * (idx / S) (S != 0: inter-pass twiddles) or idx (S == 0)
 __global__ __launch_bounds__(256) void ntt_full_table_kernel(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n,
                                                              Fr* out) {
@@ -166,6 +278,17 @@ void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, si
         }
     }
     hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(threads), lds_bytes, s, a);
+}
+void launch_ntt_pass30(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s) {
+    if (lds_bytes > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass30_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(ntt_pass30_kernel, dim3(blocks), dim3(threads), lds_bytes, s, a);
 }
 
 }  // namespace ty
