@@ -136,3 +136,33 @@ def test_full_size_vs_c_oracle(ctx, log_n):
         assert (ctx.ntt(x, log_n, inverse=True, coset=g) == CO.ntt(x, log_n, inverse=True, coset=g)).all()
     if log_n == 24:   # the quotient domain of a 2^22-row circuit: forward on the coset g = 7
         assert (ctx.ntt(x, log_n, coset=g) == CO.ntt(x, log_n, coset=g)).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_both_butterfly_kernels_give_the_c_oracles_words(built, mode, monkeypatch):
+    """The NTT has two pass kernels: 8 x 32-bit words (ff.hpp) and nine 30-bit limbs with twiddles in the 2^270 domain
+    (fr30.hpp; the default up to 2^19).  TYPLONK_NTT_FR30 = 0 / 1 / 2 selects neither / up to 2^19 / every size; each
+    mode must reproduce the C restatement of ark-poly's radix-2 FFT word for word -- forward, inverse (n^-1), coset and
+    inverse coset, one to three passes, the extremes of the input range (0, r - 1) included."""
+    import typlonk_amd
+    from oracle import coracle as CO
+
+    monkeypatch.setenv("TYPLONK_NTT_FR30", str(mode))
+    c2 = typlonk_amd.Context(0)
+    try:
+        g = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
+        g2 = np.array(O.fr_to_mont_limbs(0x123456789ABCDEF), dtype=np.uint64)
+        for log_n in (1, 2, 5, 9, 10, 11, 14, 17, 19, 20, 21):
+            x = rand_limbs(7000 + 31 * log_n + mode, 1 << log_n)
+            x[0] = 0
+            x[-1] = np.array(O.fr_to_mont_limbs(O.R - 1), dtype=np.uint64)
+            assert (c2.ntt(x, log_n) == CO.ntt(x, log_n)).all(), (mode, log_n, "forward")
+            assert (c2.ntt(x, log_n, inverse=True) == CO.ntt(x, log_n, inverse=True)).all(), (mode, log_n, "inverse")
+            assert (c2.ntt(x, log_n, coset=g) == CO.ntt(x, log_n, coset=g)).all(), (mode, log_n, "coset")
+            assert (c2.ntt(x, log_n, inverse=True, coset=g2) == CO.ntt(x, log_n, inverse=True, coset=g2)).all(), (mode, log_n, "icoset")
+            # all r - 1: the largest canonical input in every position
+            top = np.tile(np.array(O.fr_to_mont_limbs(O.R - 1), dtype=np.uint64), (1 << log_n, 1))
+            if log_n <= 17:
+                assert (c2.ntt(top, log_n) == CO.ntt(top, log_n)).all(), (mode, log_n, "all r-1")
+    finally:
+        c2.close()
