@@ -24,7 +24,11 @@ run()
 torch.cuda.synchronize()
 reps = int(os.environ.get("REPS", "5"))
 t0 = time.perf_counter()
+gap = float(os.environ.get("GAP_MS", "0")) * 1e-3   # idle time between proofs (separates them in a kernel trace)
 for _ in range(reps):
     run()
+    if gap:
+        torch.cuda.synchronize()
+        time.sleep(gap)
 torch.cuda.synchronize()
 print(f"prove log_n={log_n} batched={batched}: {(time.perf_counter() - t0) / reps * 1e3:.2f} ms per proof", flush=True)
