@@ -1723,16 +1723,6 @@ int prover_open_async(typlonk_prover* p, const Fr* poly, uint64_t m, const Fr& z
     HIPCHK(hipGetLastError());
     return TYPLONK_OK;
 }
-// evaluations of `count` <= 8 polynomials at z into slots first_slot..; stream-ordered
-int prover_eval_async(typlonk_prover* p, const Fr* const* polys, uint32_t count, uint64_t m, const Fr& z, int first_slot) {
-    Fr *blocks, *slots;
-    int rc = prover_ops_tmp(p, &blocks, &slots);
-    if (rc) return rc;
-    typlonk_ctx* ctx = p->ctx;
-    launch_eval_multi(polys, count, m, z, blocks, slots + first_slot, ctx->stream);
-    HIPCHK(hipGetLastError());
-    return TYPLONK_OK;
-}
 // one synchronisation for `count` result slots
 int prover_fetch(typlonk_prover* p, Fr* out, int count) {
     typlonk_ctx* ctx = p->ctx;
@@ -1904,21 +1894,33 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
         // quotients unless batched), 4, 5 = sigma_0, sigma_1 and 6 = the public-input polynomial at zeta (for the
         // linearisation, proof.rs:376-439, :138), 8 = Z at zeta*w (always with its quotient)
         Fr host[9];
-        const Fr* at_zeta[8];
-        uint32_t cnt = 0;
-        if (batched) {
-            for (int i = 0; i < 3; ++i) at_zeta[cnt++] = p->co[i];
-            at_zeta[cnt++] = p->z;
-        } else {
-            for (int i = 0; i < 3 && !rc; ++i) rc = prover_open_async(p, p->co[i], n, ze, p->q[i], i);
-            if (!rc) rc = prover_open_async(p, p->z, n, ze, p->q[3], 3);
+        {
+            // all of them in three launches (launch_open_multi): quotients only where the proof shape opens separately
+            Fr *blocks = nullptr, *slots = nullptr;
+            rc = prover_ops_tmp(p, &blocks, &slots);
+            const Fr* polys[8];
+            Fr* quots[8];
+            Fr* ys[8];
+            uint8_t zsel[8];
+            uint32_t cnt = 0;
+            auto item = [&](const Fr* poly, Fr* quot, int slot, uint8_t at) {
+                polys[cnt] = poly;
+                quots[cnt] = quot;
+                ys[cnt] = slots + slot;
+                zsel[cnt++] = at;
+            };
+            for (int i = 0; i < 3; ++i) item(p->co[i], batched ? nullptr : p->q[i], i, 0);
+            item(p->z, batched ? nullptr : p->q[3], 3, 0);
+            item(ce.coef + 5 * n, nullptr, 4, 0);             // sigma_0
+            item(ce.coef + 6 * n, nullptr, 5, 0);             // sigma_1
+            if (p->has_pi) item(p->pi, nullptr, 6, 0);
+            item(p->z, p->q[4], 8, 1);                        // Z at zeta * w, always with its quotient
+            if (!rc) {
+                launch_open_multi(polys, quots, ys, zsel, cnt, n, ze, zw, blocks, ctx->stream);
+                const hipError_t he = hipGetLastError();
+                if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
+            }
         }
-        const int first = batched ? 0 : 4;
-        at_zeta[cnt++] = ce.coef + 5 * n;             // sigma_0
-        at_zeta[cnt++] = ce.coef + 6 * n;             // sigma_1
-        if (p->has_pi) at_zeta[cnt++] = p->pi;
-        if (!rc) rc = prover_eval_async(p, at_zeta, cnt, n, ze, first);
-        if (!rc) rc = prover_open_async(p, p->z, n, zw, p->q[4], 8);
         // the witnesses of a, b, c at zeta need nothing else: their MSMs start on the lanes beside the context's
         // stream while the quotient below (and the linearisation after it) is still being computed
         int early = 0;

@@ -62,9 +62,11 @@ struct LincombArgs {
     uint64_t n;
     uint32_t terms;
 };
-// p_k(z) for up to 8 polynomials of m <= 2^22 coefficients each; blocks: count * ceil(m/2048) Fr; y: count Fr
-void launch_eval_multi(const Fr* const* polys, uint32_t count, uint64_t m, const Fr& z, Fr* blocks, Fr* y, hipStream_t s);
 void launch_lincomb(const LincombArgs& a, hipStream_t s);
+// count <= 8 openings (quotients[k] != null: y and (p - y)/(X - z)) or evaluations (null) of polynomials of m <= 2^22
+// coefficients, each at z0 (zsel[k] = 0) or z1 (1), in three launches; blocks: 8 * ceil(m/2048) Fr; ys[k]: device scalar
+void launch_open_multi(const Fr* const* polys, Fr* const* quotients, Fr* const* ys, const uint8_t* zsel, uint32_t count,
+                       uint64_t m, const Fr& z0, const Fr& z1, Fr* blocks, hipStream_t s);
 
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);
 // the same pass on 9 x 30-bit limbs: every table in `a` is a full table in the 2^270 domain, 36 B of LDS per element

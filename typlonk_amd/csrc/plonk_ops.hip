@@ -217,39 +217,88 @@ __global__ __launch_bounds__(256) void open_finish_kernel(OpenArgs a) {
     }
 }
 
-// ---- evaluation of up to 8 polynomials of the same length at the same point: two launches in all -----------
-struct EvalMultiArgs {
+// ---- up to 8 openings / evaluations of polynomials of the same length at one of two points: three launches in all ----
+// (round 3 of the prover: a, b, c, Z, sigma_0, sigma_1, PI at zeta and Z at zeta * w were seventeen launches of
+// 25-55 us each on the context's stream before anything else of the round could start)
+struct OpenMultiArgs {
     const Fr* c[8];
+    Fr* q[8];        // m - 1 quotient coefficients, or null: evaluation only
+    Fr* y[8];        // device scalars
+    uint8_t zsel[8]; // which of the two points
     uint64_t m;
-    Fr* blocks;     // count * nblk per-workgroup values
+    Fr* blocks;      // 8 * nblk per-workgroup values / carries
     uint32_t nblk;
-    Fr* y;          // count device scalars
-    Fr zpow[32];
+    Fr zpow[2][32];
 };
-__global__ __launch_bounds__(256) void eval_multi_block_kernel(EvalMultiArgs a) {
+__global__ __launch_bounds__(256) void open_multi_block_kernel(OpenMultiArgs a) {
     __shared__ Fr lds[256];
     Fr loc[8], ci;
-    const Fr g0 = horner_block(a.c[blockIdx.y], a.m, (uint64_t)blockIdx.x * 2048, Fr::zero(), a.zpow, 0, lds, loc, &ci);
-    if (threadIdx.x == 0) p_st(a.blocks + (uint64_t)blockIdx.y * a.nblk + blockIdx.x, g0);
+    const uint32_t k = blockIdx.y;
+    const Fr g0 = horner_block(a.c[k], a.m, (uint64_t)blockIdx.x * 2048, Fr::zero(), a.zpow[a.zsel[k]], 0, lds, loc, &ci);
+    if (threadIdx.x == 0) p_st(a.blocks + (uint64_t)k * a.nblk + blockIdx.x, g0);
 }
-// one workgroup per polynomial: p(z) = sum_b A_b (z^2048)^b
-__global__ __launch_bounds__(256) void eval_multi_top_kernel(EvalMultiArgs a) {
+__global__ __launch_bounds__(256) void open_multi_top_kernel(OpenMultiArgs a) {
     __shared__ Fr lds[256];
     Fr loc[8], ci;
-    const Fr y = horner_block(a.blocks + (uint64_t)blockIdx.x * a.nblk, a.nblk, 0, Fr::zero(), a.zpow, 11, lds, loc, &ci);
-    if (threadIdx.x == 0) p_st(a.y + blockIdx.x, y);
+    const uint32_t k = blockIdx.x;
+    const Fr* zp = a.zpow[a.zsel[k]];
+    Fr* blocks = a.blocks + (uint64_t)k * a.nblk;
+    const Fr y = horner_block(blocks, a.nblk, 0, Fr::zero(), zp, 11, lds, loc, &ci);
+    if (!a.q[k]) {
+        if (threadIdx.x == 0) p_st(a.y[k], y);  // p(z) = sum_b A_b (z^2048)^b: an evaluation is complete here
+        return;
+    }
+    const Fr zb = zp[11];
+    Fr h = ci;
+    const uint64_t s0 = (uint64_t)threadIdx.x * 8;
+    for (int e = 7; e >= 0; --e) {
+        if (s0 + e < a.nblk) p_st(blocks + s0 + e, h);
+        h = fe_add(loc[e], fe_mul(zb, h));
+    }
 }
-void launch_eval_multi(const Fr* const* polys, uint32_t count, uint64_t m, const Fr& z, Fr* blocks, Fr* y, hipStream_t s) {
-    EvalMultiArgs a;
-    for (uint32_t k = 0; k < 8; ++k) a.c[k] = polys[k < count ? k : 0];
+__global__ __launch_bounds__(256) void open_multi_finish_kernel(OpenMultiArgs a) {
+    __shared__ Fr lds[256];
+    Fr loc[8], ci;
+    const uint32_t k = blockIdx.y;
+    if (!a.q[k]) return;  // whole workgroup: no barrier is skipped by part of it
+    const Fr* zp = a.zpow[a.zsel[k]];
+    const uint64_t base = (uint64_t)blockIdx.x * 2048;
+    const Fr seed = p_ld(a.blocks + (uint64_t)k * a.nblk + blockIdx.x);
+    horner_block(a.c[k], a.m, base, seed, zp, 0, lds, loc, &ci);
+    const Fr z = zp[0];
+    Fr h = ci;
+    const uint64_t s0 = base + (uint64_t)threadIdx.x * 8;
+    for (int e = 7; e >= 0; --e) {
+        const uint64_t i = s0 + e;
+        h = fe_add(loc[e], fe_mul(z, h));
+        if (i < a.m) {
+            if (i == 0) p_st(a.y[k], h);
+            else p_st(a.q[k] + i - 1, h);
+        }
+    }
+}
+void launch_open_multi(const Fr* const* polys, Fr* const* quotients, Fr* const* ys, const uint8_t* zsel, uint32_t count,
+                       uint64_t m, const Fr& z0, const Fr& z1, Fr* blocks, hipStream_t s) {
+    OpenMultiArgs a;
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t j = k < count ? k : 0;
+        a.c[k] = polys[j];
+        a.q[k] = quotients[j];
+        a.y[k] = ys[j];
+        a.zsel[k] = zsel[j];
+    }
     a.m = m;
     a.blocks = blocks;
     a.nblk = (uint32_t)((m + 2047) / 2048);
-    a.y = y;
-    a.zpow[0] = z;
-    for (int k = 1; k < 32; ++k) a.zpow[k] = fe_sqr(a.zpow[k - 1]);
-    hipLaunchKernelGGL(eval_multi_block_kernel, dim3(a.nblk, count), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(eval_multi_top_kernel, dim3(count), dim3(256), 0, s, a);
+    a.zpow[0][0] = z0;
+    a.zpow[1][0] = z1;
+    for (int k = 1; k < 32; ++k) {
+        a.zpow[0][k] = fe_sqr(a.zpow[0][k - 1]);
+        a.zpow[1][k] = fe_sqr(a.zpow[1][k - 1]);
+    }
+    hipLaunchKernelGGL(open_multi_block_kernel, dim3(a.nblk, count), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(open_multi_top_kernel, dim3(count), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(open_multi_finish_kernel, dim3(a.nblk, count), dim3(256), 0, s, a);
 }
 
 // ---- out[i] = sum_k scalar_k * poly_k[i]  (+ constant on coefficient 0) ---------------------------------
