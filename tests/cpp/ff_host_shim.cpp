@@ -3,6 +3,7 @@
 // Python big-int oracle without a GPU.  Built by __graft_entry__.build() with g++.
 // All Fq / G1 arguments are in the C-ABI (arkworks) form: 12 u32 words per coordinate, R = 2^384.
 #include "../../typlonk_amd/csrc/g1.hpp"
+#include "../../typlonk_amd/csrc/g1_host64.hpp"
 #include <string.h>
 using namespace ty;
 
@@ -92,5 +93,38 @@ void shim_g1_chain(const uint32_t* pts, int n, int ndbl, uint32_t* o) {
     for (int i = 0; i < ndbl; ++i) acc = g1_dbl(acc);
     G1Xyzz acc2 = g1_add(acc, acc);
     sta(o, g1_to_affine(acc2));
+}
+// the 64-bit host finish (g1_host64.hpp) on the device's packed form: every point goes through the 13 x 30-bit code
+// into 48 packed words -- lifted to XYZZ with a Z derived from z, coordinates left lazily reduced, as the kernels store
+// them -- and is then read, summed, doubled and normalised by the 6 x 64-bit code.  The sum runs as
+//   ((p_0 + p_0) + (p_1 + (-p_1)) + p_2 + ... + p_{n-1}) * 2^ndbl
+// so that the doubling and the cancellation branches of the addition are taken too.  Returns 0 for the identity.
+int shim_h64_chain(const uint32_t* pts, int n, int ndbl, const uint32_t* z, uint32_t* o) {
+    namespace H = ty::h64;
+    auto dev = [&](const G1Affine& a, bool negate) {
+        G1Xyzz q = G1Xyzz::from_affine(a);
+        scramble(q, z);
+        if (negate) q.y = fq30_neg_lazy<2>(q.y);
+        q.x = fq30_add_lazy(q.x, fq30_mulk_lazy<2>(fq30_sub_lazy<2>(q.x, q.x)));  // + a multiple of p: still the same residue
+        uint32_t w[48];
+        uint32_t t[12];
+        fq30_pack(q.x, t); memcpy(w, t, 48);
+        fq30_pack(q.y, t); memcpy(w + 12, t, 48);
+        fq30_pack(q.zz, t); memcpy(w + 24, t, 48);
+        fq30_pack(q.zzz, t); memcpy(w + 36, t, 48);
+        return H::xyzz_from_device(w);
+    };
+    H::Xyzz acc = H::inf();
+    for (int i = 0; i < n; ++i) {
+        const G1Affine a = lda(pts + 24 * i);
+        if (i == 0) acc = H::xyzz_add(dev(a, false), dev(a, false));                       // doubling branch
+        else if (i == 1) acc = H::xyzz_add(acc, H::xyzz_add(dev(a, false), dev(a, true)));  // cancellation -> identity
+        else acc = H::xyzz_add(acc, dev(a, false));
+    }
+    for (int i = 0; i < ndbl; ++i) acc = H::xyzz_dbl(acc);
+    uint64_t xy[12];
+    if (!H::xyzz_to_affine(acc, xy)) return 0;
+    memcpy(o, xy, 96);
+    return 1;
 }
 }

@@ -134,6 +134,29 @@ def test_group_law_long_dependent_chain(shim):
     assert _unpt(o) == O.g1_mul(O.G1, k * pow(2, ndbl + 1, O.R) % O.R)
 
 
+def test_host_finish_on_64_bit_words_against_the_oracle(shim):
+    """g1_host64.hpp: what ends every MSM on the host (sum of the reduction's bit planes, Horner over powers of two,
+    affine normalisation) runs on 6 x 64-bit Montgomery words and reads the device's packed XYZZ form -- lazily reduced
+    13 x 30-bit limbs in 12 words, non-trivial Z.  Points built by the limb code and read back by the 64-bit code must
+    sum to what the oracle says, through the doubling branch, a cancellation, long chains, and to the identity."""
+    rnd = random.Random(64)
+    for n, ndbl in ((2, 0), (3, 1), (40, 19), (200, 40)):
+        pts = O.srs_from_secret_fast(5, n)
+        arr = np.concatenate([_pt(p) for p in pts])
+        for zs in (None, _fq(rnd.randrange(1, O.P))):
+            o = np.zeros(12, dtype=np.uint64)
+            ok = shim.shim_h64_chain(u32p(arr), n, ndbl, None if zs is None else u32p(zs), u32p(o))
+            k = (2 + sum(pow(5, i, O.R) for i in range(2, n))) * pow(2, ndbl, O.R) % O.R   # 2 p_0 + 0 + p_2 + ...
+            assert ok == 1 and _unpt(o) == O.g1_mul(O.G1, k), (n, ndbl)
+    # p_0 + p_0 with p_0 = the point of order dividing... a sum that IS the identity: G + G, then (2G) + (-2G) needs n = 2 only
+    g2 = O.g1_mul(O.G1, 2)
+    arr = np.concatenate([_pt(O.g1_neg(O.G1)), _pt(g2)])   # 2 * (-G) + (2G + (-2G)) = -2G: not the identity; identity next
+    o = np.zeros(12, dtype=np.uint64)
+    assert shim.shim_h64_chain(u32p(arr), 2, 0, None, u32p(o)) == 1 and _unpt(o) == O.g1_neg(g2)
+    arr = np.concatenate([_pt(None), _pt(g2)])             # inf + inf + (2G - 2G)
+    assert shim.shim_h64_chain(u32p(arr), 2, 3, None, u32p(o)) == 0
+
+
 def test_library_loads_and_exports_every_declared_symbol(built):
     import typlonk_amd
     from typlonk_amd.capi import SYMBOLS

@@ -4,6 +4,7 @@
 // device typlonk_init fails with TYPLONK_ERR_NO_DEVICE.
 #include "../../include/typlonk.h"
 #include "g1.hpp"
+#include "g1_host64.hpp"
 #include "launch.hpp"
 #include "transcript.hpp"
 
@@ -940,38 +941,44 @@ int msm_finish(typlonk_ctx* ctx, MsmWs& ws) {
     if (!ws.pending) return TYPLONK_OK;
     ws.pending = false;
     HIPCHK(hipStreamSynchronize(ws.stream));
+    // host arithmetic on 6 x 64-bit words (g1_host64.hpp): a third of the time of the 13 x 30-bit limb code here
+    namespace H = h64;
+    auto out = [&](const H::Xyzz& acc) {
+        if (H::xyzz_to_affine(acc, ws.out_xy)) *ws.out_inf = 0;
+        else write_affine_out(G1Affine::inf(), ws.out_xy, ws.out_inf);
+    };
     if (ws.rc) {
         // bit planes -> points by power of two: set j (offset c*j; 0 in table mode), rows carry 2^shift
         const RcShape& sh = ws.rcs;
-        std::vector<G1Xyzz> pe(ws.c * sh.nsets + 2 * RC_NB + sh.cl + 2, G1Xyzz::inf());
+        std::vector<H::Xyzz> pe(ws.c * sh.nsets + 2 * RC_NB + sh.cl + 2, H::inf());
         int top = -1;
         for (uint32_t j = 0; j < sh.nsets; ++j) {
             uint32_t nbr, nbc, shift;
             rc_bits(sh, j, &nbr, &nbc, &shift);
             for (uint32_t kind = 0; kind < 2; ++kind)
                 for (uint32_t b = 0; b < (kind ? nbc : nbr); ++b) {
-                    const G1Xyzz pt = unpack_xyzz(ws.host_wins + (size_t)((j * 2 + kind) * RC_NB + b) * 48);
-                    if (pt.is_inf()) continue;
+                    const H::Xyzz pt = H::xyzz_from_device(ws.host_wins + (size_t)((j * 2 + kind) * RC_NB + b) * 48);
+                    if (H::is_inf(pt)) continue;
                     const uint32_t e = ws.c * j + b + (kind ? 0u : shift);
-                    pe[e] = g1_add(pe[e], pt);
+                    pe[e] = H::xyzz_add(pe[e], pt);
                     top = std::max(top, (int)e);
                 }
         }
-        G1Xyzz acc = G1Xyzz::inf();
+        H::Xyzz acc = H::inf();
         for (int e = top; e >= 0; --e) {
-            if (!acc.is_inf()) acc = g1_dbl(acc);
-            if (!pe[e].is_inf()) acc = g1_add(acc, pe[e]);
+            if (!H::is_inf(acc)) acc = H::xyzz_dbl(acc);
+            if (!H::is_inf(pe[e])) acc = H::xyzz_add(acc, pe[e]);
         }
-        write_affine_out(g1_to_affine(acc), ws.out_xy, ws.out_inf);
+        out(acc);
         return TYPLONK_OK;
     }
-    G1Xyzz acc = G1Xyzz::inf();
+    H::Xyzz acc = H::inf();
     for (int j = (int)ws.W - 1; j >= 0; --j) {
-        if (!acc.is_inf())
-            for (uint32_t d = 0; d < ws.c; ++d) acc = g1_dbl(acc);
-        acc = g1_add(acc, unpack_xyzz(ws.host_wins + (size_t)j * 48));
+        if (!H::is_inf(acc))
+            for (uint32_t d = 0; d < ws.c; ++d) acc = H::xyzz_dbl(acc);
+        acc = H::xyzz_add(acc, H::xyzz_from_device(ws.host_wins + (size_t)j * 48));
     }
-    write_affine_out(g1_to_affine(acc), ws.out_xy, ws.out_inf);
+    out(acc);
     return TYPLONK_OK;
 }
 

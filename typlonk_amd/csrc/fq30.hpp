@@ -448,7 +448,7 @@ TY_HD void fq30_to_ark(const Fq30& a, uint32_t (&w)[12]) {
     fq30_pack(fq30_canon(fq30_mul(a, c)), w);
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
+// (plain host functions: the device pass parses them -- host code in the .hip units names them -- and emits nothing)
 // Host-side inversion by the binary extended Euclid algorithm on six 64-bit words: ~10 us instead of the ~50 us of the
 // Fermat ladder below.  It is the last step of every MSM (canonical affine output, g1_to_affine), on the host's critical
 // path.  Data-dependent branches are no concern here: the inverted value is a projective denominator of a public result.
@@ -491,18 +491,11 @@ inline void fq30_u384_half_mod(Fq30U384& x, const Fq30U384& p) {
         fq30_u384_shr1(x, 0);
     }
 }
-inline Fq30 fq30_inv_gcd(const Fq30& a) {
+// u^-1 mod p for a plain integer 0 < u < p: binary extended Euclid on 64-bit words
+inline Fq30U384 fq30_u384_modinv(Fq30U384 u) {
     static const Fq30U384 P = {{0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull,
                                 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull}};
-    const Fq30 c = fq30_canon(a);
-    if (fq30_is_zero_exact(c)) return fq30_zero();
-    // the residue itself, as a plain integer < p
-    Fq30U384 u = {{0, 0, 0, 0, 0, 0}}, v = P, x1 = {{1, 0, 0, 0, 0, 0}}, x2 = {{0, 0, 0, 0, 0, 0}};
-    for (int i = 0; i < 13; ++i) {
-        const int bit = 30 * i, wi = bit >> 6, sh = bit & 63;
-        u.w[wi] |= (uint64_t)c.v[i] << sh;
-        if (sh > 34 && wi + 1 < 6) u.w[wi + 1] |= (uint64_t)c.v[i] >> (64 - sh);
-    }
+    Fq30U384 v = P, x1 = {{1, 0, 0, 0, 0, 0}}, x2 = {{0, 0, 0, 0, 0, 0}};
     // invariant: x1 * residue = u, x2 * residue = v (mod p)
     while (!fq30_u384_is_one(u) && !fq30_u384_is_one(v)) {
         while (!(u.w[0] & 1)) {
@@ -523,7 +516,19 @@ inline Fq30 fq30_inv_gcd(const Fq30& a) {
             fq30_u384_sub(x2, x1);
         }
     }
-    const Fq30U384& inv = fq30_u384_is_one(u) ? x1 : x2;  // residue^-1 as a plain integer < p
+    return fq30_u384_is_one(u) ? x1 : x2;
+}
+inline Fq30 fq30_inv_gcd(const Fq30& a) {
+    const Fq30 c = fq30_canon(a);
+    if (fq30_is_zero_exact(c)) return fq30_zero();
+    // the residue itself, as a plain integer < p
+    Fq30U384 u = {{0, 0, 0, 0, 0, 0}};
+    for (int i = 0; i < 13; ++i) {
+        const int bit = 30 * i, wi = bit >> 6, sh = bit & 63;
+        u.w[wi] |= (uint64_t)c.v[i] << sh;
+        if (sh > 34 && wi + 1 < 6) u.w[wi + 1] |= (uint64_t)c.v[i] >> (64 - sh);
+    }
+    const Fq30U384 inv = fq30_u384_modinv(u);  // residue^-1 as a plain integer < p
     Fq30 r;
     for (int i = 0; i < 13; ++i) {
         const int bit = 30 * i, wi = bit >> 6, sh = bit & 63;
@@ -538,7 +543,6 @@ inline Fq30 fq30_inv_gcd(const Fq30& a) {
     for (int i = 0; i < 13; ++i) k.v[i] = R3[i];
     return fq30_mul(r, k);
 }
-#endif
 
 // Fermat ladder a^(p-2): the device form (srs_gen.hip), and the reference the host's Euclid inversion is tested against
 TY_HD Fq30 fq30_inv_fermat(const Fq30& a);
