@@ -2186,18 +2186,22 @@ void* typlonk_buf_devptr(const typlonk_buf* buf) { return buf ? (void*)buf->d : 
 
 int typlonk_g1_sum_host(const uint64_t* xy, const uint8_t* inf, size_t count, uint64_t out_xy[12], uint8_t* out_inf) {
     if ((!xy && count) || !out_xy || !out_inf) return TYPLONK_ERR_INVALID_ARG;
-    G1Xyzz acc = G1Xyzz::inf();
+    // arkworks' words ARE the 6 x 64-bit Montgomery form of g1_host64.hpp: no conversion in or out
+    namespace H = h64;
+    const H::Fq one = {{0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull, 0x77ce585370525745ull,
+                        0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull}};  // 2^384 mod p
+    H::Xyzz acc = H::inf();
     for (size_t i = 0; i < count; ++i) {
         if (inf && inf[i]) continue;
-        G1Affine p;
-        uint32_t w[12];
-        memcpy(w, xy + i * 12, 48);
-        p.x = fq30_from_ark(w);
-        memcpy(w, xy + i * 12 + 6, 48);
-        p.y = fq30_from_ark(w);
-        g1_madd(acc, p, false);
+        H::Xyzz p;
+        memcpy(p.x.v, xy + i * 12, 48);
+        memcpy(p.y.v, xy + i * 12 + 6, 48);
+        p.zz = one;
+        p.zzz = one;
+        acc = H::xyzz_add(acc, p);
     }
-    write_affine_out(g1_to_affine(acc), out_xy, out_inf);
+    if (H::xyzz_to_affine(acc, out_xy)) *out_inf = 0;
+    else write_affine_out(G1Affine::inf(), out_xy, out_inf);
     return TYPLONK_OK;
 }
 
