@@ -711,21 +711,6 @@ void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf) 
     }
 }
 
-// packed device words -> host XYZZ
-G1Xyzz unpack_xyzz(const uint32_t* p) {
-    G1Xyzz r;
-    uint32_t w[12];
-    memcpy(w, p, 48);
-    r.x = fq30_unpack(w);
-    memcpy(w, p + 12, 48);
-    r.y = fq30_unpack(w);
-    memcpy(w, p + 24, 48);
-    r.zz = fq30_unpack(w);
-    memcpy(w, p + 36, 48);
-    r.zzz = fq30_unpack(w);
-    return r;
-}
-
 // Launch every kernel of one m-term MSM (m > 0, validated by the caller) on `stream` using workspace
 // `ws`, ending with the asynchronous copy of the W window sums into ws.host_wins.
 int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry& srs, const Fr* d_scalars, size_t m,
