@@ -217,10 +217,24 @@ class DeviceBuffer:
             self.handle = C.c_void_p()
 
 
+def _torch_first() -> None:
+    """PyTorch wheels bundle their own HIP / HSA runtime next to the system one this library links (/opt/rocm).  The two
+    coexist in one process when PyTorch brings the device up first (bench.py, torch.distributed); the other way round
+    PyTorch afterwards reports "no ROCm-capable device".  Callers that never import torch are not affected, and nothing
+    here is required for the C ABI -- this only fixes the order for Python processes that use both."""
+    try:
+        import torch
+    except ImportError:
+        return
+    if torch.cuda.is_available():
+        torch.cuda.init()
+
+
 class Context:
     """typlonk_ctx: one HIP device, its stream, MSM workspaces and cached NTT plans."""
 
     def __init__(self, device: int = 0):
+        _torch_first()
         self.lib = load_library()
         self.h = C.c_void_p()
         rc = self.lib.typlonk_init(C.byref(self.h), device)

@@ -824,7 +824,8 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             StageTimer st(ctx, "msm_sort", ss);
             launch_msm_segsort(sc, (uint64_t)mk, c, W, digit_v, (uint32_t)seg.hb, seg.ibits, tables ? (uint32_t)srs.len : 0u,
                                tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums, keys,
-                               counts, offsets, sorted, ss);
+                               counts, offsets, sorted, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p,
+                               (uint32_t*)sb.tasks.p, ss);
         } else {
             {
                 StageTimer st(ctx, "msm_digits", ss);
@@ -843,7 +844,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         {
             StageTimer st(ctx, "msm_order", ss);
             launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.order.p,
-                                (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, ss);
+                                (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, /*hist_done=*/segsort, ss);
         }
         if (ss != s) {
             HIPCHK(hipEventRecord(ws.ev_sorted[k], ss));

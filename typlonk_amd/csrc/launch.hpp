@@ -82,10 +82,10 @@ uint32_t msm_segsort_blocks(uint64_t m);  // workgroups of the level-1 passes fo
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
-                        hipStream_t s);
+                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, hipStream_t s);
 void launch_srs_tables(uint32_t* pts, uint64_t len, uint32_t c, uint32_t T, hipStream_t s);
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
-                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, hipStream_t s);
+                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, bool hist_done, hipStream_t s);
 void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist514, const uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s);
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,

@@ -97,9 +97,12 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint32_t* in
 }
 
 // single block: exclusive scan of nblocks values in place (nblocks arbitrary, processed in chunks)
-__global__ __launch_bounds__(256) void scan_top_kernel(uint32_t* block_sums, uint32_t nblocks) {
+// (also clears `zero` [0, nzero): the bucket-schedule counters the segment sort adds into two launches later -- a
+// hipMemsetAsync of 2 KB costs two 7-us fill kernels on the stream)
+__global__ __launch_bounds__(256) void scan_top_kernel(uint32_t* block_sums, uint32_t nblocks, uint32_t* zero, uint32_t nzero) {
     __shared__ uint32_t buf[256];
     __shared__ uint32_t running;
+    for (uint32_t i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
     for (uint32_t base = 0; base < nblocks; base += 256) {
@@ -280,10 +283,13 @@ __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars
 // one workgroup per segment: count by low bits, local exclusive scan -> bucket counts/offsets,
 // then the final scatter.  The segment is read twice from L2; only a 256-bin histogram lives in LDS,
 // so any segment length works.
+// It also does what order_hist_kernel does for its own 2^lb buckets (their sizes are in registers here): the size
+// histogram of the bucket schedule and the task lists of heavy buckets -- one launch and one pass over counts[] fewer.
 __global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __restrict__ entries,
                                                            const uint32_t* __restrict__ blk_base, MsmShape sh,
                                                            uint32_t total_slot, uint32_t* counts, uint32_t* offsets,
-                                                           uint32_t* sorted) {
+                                                           uint32_t* sorted, uint32_t cap, uint32_t* ohist, uint32_t* heavy,
+                                                           uint32_t* tasks) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t pref[256];
     const uint32_t s = blockIdx.x;
@@ -313,7 +319,33 @@ __global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __res
         counts[bucket] = mine;
         offsets[bucket] = start + excl;
         if (s + 1 == sh.nseg && threadIdx.x + 1 == nlow) offsets[bucket + 1] = end;
+        if (mine > cap) {  // heavy bucket: the accumulate kernel takes the first cap entries, tasks the rest
+            const uint32_t k = (mine - cap + cap - 1) / cap;
+            const uint32_t hi = atomicAdd(&ohist[512], 1u);
+            const uint32_t t0 = atomicAdd(&ohist[513], k);
+            heavy[3 * hi] = bucket;
+            heavy[3 * hi + 1] = t0;
+            heavy[3 * hi + 2] = k;
+            uint32_t b = start + excl + cap;
+            const uint32_t e = start + excl + mine;
+            for (uint32_t t = 0; t < k; ++t) {
+                tasks[2 * (t0 + t)] = b;
+                tasks[2 * (t0 + t) + 1] = min(b + cap, e);
+                b += cap;
+            }
+        }
     }
+    __syncthreads();
+    // schedule histogram: hist[] is free until the scatter below re-zeroes... it IS the scatter's counter array, so the
+    // size bins are counted in pref-independent LDS first: reuse `hist` now, clear it again before the scatter
+    if (threadIdx.x < nlow) atomicAdd(&hist[min(mine, 255u)], 1u);
+    __syncthreads();
+    {
+        const uint32_t nbin = hist[threadIdx.x];
+        if (nbin) atomicAdd(&ohist[threadIdx.x], nbin);
+    }
+    __syncthreads();
+    hist[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t e = start + threadIdx.x; e < end; e += 256) {
         const uint32_t v = entries[e];
@@ -420,15 +452,15 @@ void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint3
                  hipStream_t s) {
     const uint32_t nblk = (uint32_t)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblk), dim3(256), 0, s, counts, n, block_sums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, nblk);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, nblk, (uint32_t*)nullptr, 0u);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(nblk), dim3(256), 0, s, counts, n, block_sums, offsets, cursor);
 }
 // plain exclusive scan of n counters into out[0..n] (out[n] = total); scratch: ceil(n/2048) u32
 void launch_exclusive_scan(const uint32_t* in, uint64_t n, uint32_t* block_sums, uint32_t* out, uint32_t* out2,
-                           hipStream_t s) {
+                           uint32_t* zero, uint32_t nzero, hipStream_t s) {
     const uint32_t nblk = (uint32_t)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblk), dim3(256), 0, s, in, n, block_sums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, nblk);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, nblk, zero, nzero);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(nblk), dim3(256), 0, s, in, n, block_sums, out, out2);
 }
 
@@ -437,7 +469,7 @@ uint32_t msm_segsort_blocks(uint64_t m) { return (uint32_t)((m + msm_chunk_for(m
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
-                        hipStream_t s) {
+                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, hipStream_t s) {
     MsmShape sh;
     sh.c = c;
     sh.W = W;
@@ -455,19 +487,22 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
     const uint32_t nt1 = msm_seg1_threads();
     hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
                        blk_hist);
-    launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, s);
+    launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, 514u, s);
     hipLaunchKernelGGL(msm_seg_scatter_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
                        blk_base, entries);
     hipLaunchKernelGGL(msm_seg_sort_kernel, dim3(sh.nseg), dim3(256), 0, s, entries, blk_base, sh, (uint32_t)nmat, counts,
-                       offsets, sorted);
+                       offsets, sorted, cap, hist514, heavy, tasks);
 }
 
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
-                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, hipStream_t s) {
-    // hist514: histogram (256) + running bases (256) + heavy-bucket and task counters (2)
-    (void)hipMemsetAsync(hist514, 0, 514 * sizeof(uint32_t), s);
+                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, bool hist_done, hipStream_t s) {
+    // hist514: histogram (256) + running bases (256) + heavy-bucket and task counters (2); hist_done: the segment sort
+    // has filled the histogram and the heavy-bucket lists already (launch_msm_segsort)
     const uint32_t nblk = (n + 255) / 256;
-    hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, offsets, n, cap, hist514, heavy, tasks);
+    if (!hist_done) {
+        (void)hipMemsetAsync(hist514, 0, 514 * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, offsets, n, cap, hist514, heavy, tasks);
+    }
     hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist514, hist514 + 256);
     hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514 + 256, order);
 }
