@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <set>
+#include <string>
+#include <vector>
 
 #include "../../typlonk_amd/host/circuit_host.hpp"
 
@@ -52,6 +54,46 @@ struct Chain : plonk::CircuitDescription<1, Chain<N>> {  // x -> x^2 -> x^4 ... 
     }
 };
 
+static void print_fr(const Fr& f);
+// A circuit description as data (the same generator lives in the Python oracle of the front end,
+// random_program): x <- x * 6364136223846793005 + 1442695040888963407, take x >> 33; per step kind = r % 8
+// (0..2 add, 3..5 mul, 6..7 assert_eq), operands = two draws modulo the number of variables so far.
+struct Op {
+    int kind;  // 0 add, 1 mul, 2 eq
+    size_t a, b;
+};
+static std::vector<Op> g_program;
+static void make_program(uint64_t seed, size_t n_inputs, size_t n_ops) {
+    g_program.clear();
+    uint64_t x = seed;
+    auto draw = [&]() {
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        return x >> 33;
+    };
+    size_t nvars = n_inputs;
+    for (size_t i = 0; i < n_ops; ++i) {
+        const uint64_t kind = draw() % 8;
+        const size_t a = draw() % nvars, b = draw() % nvars;
+        if (kind <= 5) {
+            g_program.push_back({kind <= 2 ? 0 : 1, a, b});
+            ++nvars;
+        } else {
+            g_program.push_back({2, a, b});
+        }
+    }
+}
+struct Programmed : plonk::CircuitDescription<3, Programmed> {
+    template <class V>
+    static void run(std::array<V, 3> in) {
+        std::vector<V> v(in.begin(), in.end());
+        for (const Op& op : g_program) {
+            if (op.kind == 0) v.push_back(v[op.a] + v[op.b]);
+            else if (op.kind == 1) v.push_back(v[op.a] * v[op.b]);
+            else v[op.a].assert_eq(v[op.b]);
+        }
+    }
+};
+
 // the cycles of a permutation as a set of sorted cell sets
 static std::set<std::set<size_t>> cycles(const std::vector<size_t>& perm) {
     std::set<std::set<size_t>> out;
@@ -72,7 +114,36 @@ static void print_fr(const Fr& f) {
     for (int k = 7; k >= 0; --k) std::printf("%08x", c.v[k]);
 }
 
-int main() {
+// `test_circuit_tables_host random <seed> <ops>`: the tables and the witness (inputs 3, 4, 5) of a generated circuit
+static int random_mode(uint64_t seed, size_t ops) {
+    make_program(seed, 3, ops);
+    plonk::CircuitTables t;
+    try {
+        t = plonk::compile_tables<3, Programmed>();
+    } catch (const std::exception& e) {
+        std::printf("dangling\n");
+        return 0;
+    }
+    std::printf("rows=%zu\ngates=", t.rows);
+    for (plonk::Gate g : t.gates) std::printf("%c", g == plonk::Gate::Mul ? 'M' : (g == plonk::Gate::Add ? 'A' : 'D'));
+    std::printf("\nperm=");
+    for (size_t k = 0; k < t.permutation.perm.size(); ++k) std::printf("%zu%s", t.permutation.perm[k], k + 1 < t.permutation.perm.size() ? "," : "\n");
+    auto rec = std::make_shared<plonk::Advice>();
+    std::array<plonk::ComputeVar, 3> in = {plonk::ComputeVar(Fr(3), rec), plonk::ComputeVar(Fr(4), rec), plonk::ComputeVar(Fr(5), rec)};
+    Programmed::run<plonk::ComputeVar>(in);
+    for (int c = 0; c < 3; ++c) {
+        std::printf("w%d=", c);
+        for (size_t j = 0; j < rec->col[c].size(); ++j) {
+            print_fr(rec->col[c][j]);
+            std::printf(j + 1 < rec->col[c].size() ? "," : "");
+        }
+        std::printf("\n");
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc == 4 && std::string(argv[1]) == "random") return random_mode(std::strtoull(argv[2], nullptr, 10), std::strtoull(argv[3], nullptr, 10));
     // ---- permutation builder on its own ----
     {
         auto pb = plonk::PermutationBuilder<3>::with_rows(4);

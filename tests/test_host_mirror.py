@@ -84,6 +84,32 @@ def test_front_end_tables_equal_the_hand_laid_oracle_tables(built):
         assert [int(x, 16) for x in lines[f"sigma{i}"].split(",")] == sig[i]
 
 
+@pytest.mark.parametrize("seed,ops", [(1, 5), (2, 12), (3, 40), (6, 6), (7, 20), (10, 6), (11, 200), (12, 200), (99, 1000), (100, 3000)])
+def test_front_end_on_generated_circuits_against_its_python_oracle(built, seed, ops):
+    """the C++ front end and oracle/frontend.py (a separate restatement of builder.rs / permutation lib.rs) interpret the
+    same generated description -- additions, multiplications and assert_eq over earlier variables, reuse of one variable
+    many times, equalities on variables that never enter a gate: same padded size, same gate rows, same partition of the
+    cells into copy-constraint cycles, same witness columns; a description the reference would panic on fails in both"""
+    from oracle import frontend as F
+
+    exe = os.path.join(ROOT, "tests", "cpp", "test_circuit_tables_host")
+    r = subprocess.run([exe, "random", str(seed), str(ops)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    prog = F.random_program(seed, 3, ops)
+    try:
+        rows, gates, _, perm = F.compile_circuit(F.run_program(prog), 3)
+    except ValueError:
+        assert r.stdout.strip() == "dangling"
+        return
+    lines = dict(l.split("=", 1) for l in r.stdout.splitlines() if "=" in l)
+    assert int(lines["rows"]) == rows and lines["gates"] == "".join(gates)
+    assert _cycles([int(x) for x in lines["perm"].split(",")]) == F.cycles(perm)
+    adv = F.witness(F.run_program(prog), [3, 4, 5])
+    for c in range(3):
+        got = [int(x, 16) for x in lines[f"w{c}"].split(",")] if lines[f"w{c}"] else []
+        assert got == adv[c]
+
+
 @pytest.mark.gpu
 def test_reference_circuit_tests_through_the_cpp_front_end(built):
     """plonk/src/builder/test.rs (circuit2_test, circuit2_test_bad_inputs, circuit1_test) written against the C++ mirror:

@@ -237,3 +237,24 @@ def test_readme_circuit_prove_and_verify_on_cpu():
     assert ok and proof["r_open"][1] == 0
     bad, _ = _cpu_prove_verify([3, 4, 6])
     assert not bad
+
+
+def test_front_end_oracle_reproduces_kat5():
+    """oracle/frontend.py on the README circuit: the tables SURVEY.md KAT-5 lists (4 gates -> 8 rows, Mul Mul Mul Add,
+    the six copy constraints as transpositions, witness columns a, b, c) and the hand-laid ones of plonk_oracle.py"""
+    from oracle import frontend as F
+
+    def readme(v):
+        a, b, c = v
+        a2, b2, c2 = a * a, b * b, c * c
+        (a2 + b2).assert_eq(c2)
+
+    rows, gates, sel, perm = F.compile_circuit(readme, 3)
+    assert rows == 8 and "".join(gates) == "MMMADDDD"
+    log_n, cols, q, pperm = PO.pythagorean_circuit([3, 4, 5])
+    assert sel == [[q[k][j] for k in ("q_l", "q_r", "q_o", "q_m", "q_c")] for j in range(8)]
+    assert F.cycles(perm) == F.cycles(pperm)
+    assert {frozenset(c) for c in F.cycles(perm) if len(c) > 1} == {frozenset(p) for p in ((0, 8), (1, 9), (2, 10), (16, 3), (17, 11), (19, 18))}
+    assert F.witness(readme, [3, 4, 5]) == ([3, 4, 5, 9], [3, 4, 5, 16], [9, 16, 25, 25])
+    with pytest.raises(ValueError):
+        F.compile_circuit(lambda v: v[0].assert_eq(v[1]), 2)
