@@ -243,6 +243,7 @@ def test_front_end_oracle_reproduces_kat5():
     """oracle/frontend.py on the README circuit: the tables SURVEY.md KAT-5 lists (4 gates -> 8 rows, Mul Mul Mul Add,
     the six copy constraints as transpositions, witness columns a, b, c) and the hand-laid ones of plonk_oracle.py"""
     from oracle import frontend as F
+    from oracle import plonk_oracle as PO
 
     def readme(v):
         a, b, c = v
