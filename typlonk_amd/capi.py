@@ -74,6 +74,15 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own HIP / HSA runtime next to the system one this library links (/opt/rocm).  One
+    # process can hold both only if PyTorch's copy is loaded FIRST (its libraries are global, so the system runtime
+    # loaded afterwards shares its HSA layer); the other way round two independent HSA runtimes come up and whichever
+    # initialises second reports "no device".  Importing torch here -- when it is installed -- fixes the order for every
+    # Python process that uses both; C, C++ and Rust callers never see any of this.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the MSM/NTT path has no CPU fallback)")
@@ -217,24 +226,10 @@ class DeviceBuffer:
             self.handle = C.c_void_p()
 
 
-def _torch_first() -> None:
-    """PyTorch wheels bundle their own HIP / HSA runtime next to the system one this library links (/opt/rocm).  The two
-    coexist in one process when PyTorch brings the device up first (bench.py, torch.distributed); the other way round
-    PyTorch afterwards reports "no ROCm-capable device".  Callers that never import torch are not affected, and nothing
-    here is required for the C ABI -- this only fixes the order for Python processes that use both."""
-    try:
-        import torch
-    except ImportError:
-        return
-    if torch.cuda.is_available():
-        torch.cuda.init()
-
-
 class Context:
     """typlonk_ctx: one HIP device, its stream, MSM workspaces and cached NTT plans."""
 
     def __init__(self, device: int = 0):
-        _torch_first()
         self.lib = load_library()
         self.h = C.c_void_p()
         rc = self.lib.typlonk_init(C.byref(self.h), device)
