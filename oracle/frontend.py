@@ -10,7 +10,7 @@ Restates, in plain Python,
   * Gate::to_row                             /root/reference/plonk/src/builder.rs:314-324
   * PermutationBuilder::{add_constrain, build}  /root/reference/permutation/src/lib.rs:46-93
 
-so that the C++ front end (typlonk_amd/host/circuit_host.hpp) can be compared with it on arbitrary circuits.  The
+so that the C++ front end (tests/cpp/circuit_host.hpp) can be compared with it on arbitrary circuits.  The
 reference iterates its constraints in HashMap order (lib.rs:68): the partition into cycles is defined, the order inside
 a cycle is not -- comparisons are made on the partition.  Pinned by the README circuit, whose tables SURVEY.md KAT-5
 lists (tests/test_oracle.py).  Only tests/ may import it.

@@ -33,8 +33,8 @@
 #include <unordered_map>
 #include <utility>
 
-#include "../csrc/transcript.hpp"
-#include "typlonk_host.hpp"
+#include "../../typlonk_amd/csrc/transcript.hpp"
+#include "../../typlonk_amd/host/typlonk_host.hpp"
 
 namespace typlonk {
 namespace plonk {

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "../../typlonk_amd/host/circuit_host.hpp"
+#include "circuit_host.hpp"
 
 using namespace typlonk;
 

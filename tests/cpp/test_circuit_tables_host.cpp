@@ -1,4 +1,4 @@
-// The front end of the C++ mirror (typlonk_amd/host/circuit_host.hpp) without a GPU: the recording run of the
+// The front end of the C++ mirror (tests/cpp/circuit_host.hpp, test harness) without a GPU: the recording run of the
 // reference's two test circuits (plonk/src/builder/test.rs:3-24), the permutation builder, the witness of the computing
 // run.  Prints the tables of the README circuit for tests/test_host_mirror.py to compare with the tables
 // oracle/plonk_oracle.py lays out by hand.
@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../../typlonk_amd/host/circuit_host.hpp"
+#include "circuit_host.hpp"
 
 using namespace typlonk;
 using plonk::Tag;

@@ -319,10 +319,10 @@ def test_gpu_proof_passes_the_reference_verifier_with_real_pairings(ctx):
 
 
 def test_prove_with_the_transcript_and_verify_by_recomputing_challenges(ctx):
-    """prove() without injected challenges uses typlonk_amd/transcript.py (the reference's ChallengeGenerator); the
+    """prove() without injected challenges squeezes them natively (csrc/transcript.hpp, the reference's ChallengeGenerator); the
     verifier side recomputes them from the commitments as verify_challenges does (proof.rs:236-246)"""
     from oracle import pairing as PR
-    from typlonk_amd import transcript as T
+    import transcript_ref as T
 
     log_n = 4
     n, cols, q_evals, perm, cid = _setup(ctx, log_n)
@@ -358,7 +358,7 @@ def test_native_prove_equals_the_round_by_round_flow(ctx, log_n):
     """typlonk_prove (one native call, transcript in csrc/transcript.hpp) returns exactly what Context.prove assembles
     from the three rounds with the Python statement of the transcript -- commitments, witnesses, evaluations -- and the
     challenges it used are the ones recomputed from its own commitments (verify_challenges, proof.rs:236-246)"""
-    from typlonk_amd import transcript as T
+    import transcript_ref as T
     from typlonk_amd.capi import ERR_UNSATISFIED, TyplonkError
 
     n, cols, q_evals, perm, cid = _setup(ctx, log_n)

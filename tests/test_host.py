@@ -220,11 +220,11 @@ def test_product_never_imports_oracle():
                     assert not pat.search(src), f"{f} references the oracle"
 
 
-# ---- Fiat-Shamir transcript (typlonk_amd/transcript.py; unverifiable against Rust here, see its docstring) -------
+# ---- Fiat-Shamir transcript (tests/transcript_ref.py, the harness's separate Python statement; unverifiable against Rust here, see its docstring) -------
 def test_transcript_building_blocks():
     import struct
 
-    from typlonk_amd import transcript as T
+    import transcript_ref as T
 
     # ChaCha block function against RFC 7539 section 2.3.2 (20 rounds; the reference's StdRng runs 12)
     key = list(struct.unpack("<8I", bytes(range(32))))
@@ -252,12 +252,12 @@ def test_transcript_building_blocks():
 
 def test_native_transcript_equals_the_python_statement(built):
     """typlonk_transcript_challenges (csrc/transcript.hpp: Blake2b-512, PCG32 seed expansion, ChaCha12, Fr::rand,
-    serialize_unchecked) against typlonk_amd/transcript.py (hashlib Blake2b + an independent ChaCha): two restatements
+    serialize_unchecked) against tests/transcript_ref.py (hashlib Blake2b + an independent ChaCha): two restatements
     of plonk/src/proof/challenges.rs:9-46 written separately must agree bit for bit -- 0..6 commitments (0, 96, ... 576
     bytes: below, at and across Blake2b's 128-byte blocks), the point at infinity included"""
     import random
 
-    from typlonk_amd import transcript as T
+    import transcript_ref as T
     from typlonk_amd.capi import transcript_challenges
 
     rnd = random.Random(77)

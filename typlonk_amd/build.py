@@ -80,7 +80,7 @@ def build_host_tests(force: bool = False) -> list[str]:
     """test binaries of the C++ host mirror (typlonk_amd/host/typlonk_host.hpp), linked to the HIP library"""
     outs = []
     hdr = [os.path.join(ROOT, "typlonk_amd", "host", "typlonk_host.hpp"), os.path.join(ROOT, "typlonk_amd", "host", "pairing_host.hpp"),
-           os.path.join(ROOT, "typlonk_amd", "host", "circuit_host.hpp"),
+           os.path.join(ROOT, "tests", "cpp", "circuit_host.hpp"),
            os.path.join(CSRC, "ff.hpp"), os.path.join(CSRC, "fq30.hpp"), os.path.join(CSRC, "g1_host64.hpp"),
            os.path.join(CSRC, "transcript.hpp"), LIB]
     for name in ("test_poly_host", "test_kzg_host", "test_plonk_host", "test_pairing_host", "test_circuit_tables_host", "test_circuit_host"):

@@ -413,10 +413,9 @@ class Context:
         reference panics in vanishes() or hands its verifier a proof it rejects, plonk/src/proof.rs:321, 361, 234)."""
         fold = fold or (lambda pts: pts)
         if challenge12 is None or challenge34 is None:
-            # the reference's own Fiat-Shamir (plonk/src/proof/challenges.rs), see typlonk_amd/transcript.py
-            from . import transcript as _t
-            challenge12 = challenge12 or _t.challenge12
-            challenge34 = challenge34 or _t.challenge34
+            # the reference's own Fiat-Shamir (plonk/src/proof/challenges.rs), native: csrc/transcript.hpp
+            challenge12 = challenge12 or (lambda pts: transcript_challenges(pts, 2))
+            challenge34 = challenge34 or (lambda pts: transcript_challenges(pts, 2))
         lib = self.lib
         w = (C.c_void_p * 3)(*[b.handle.value for b in wire_evals])
         pr = C.c_void_p()

@@ -8,7 +8,7 @@
 // are not in this container (ark-serialize / ark-ec / ark-ff 0.3.0, rand 0.8.4 = rand_chacha 0.3.1 ChaCha12,
 // rand_core 0.6.3; pins in /root/reference/Cargo.lock:28-29, 42-43, 95-96, 435-436, 447-448, 457-458) and there is no
 // Rust toolchain here: the code follows the published crate behaviour and is NOT verified against the reference.  It is
-// pinned against the independent Python statement (typlonk_amd/transcript.py, tests/test_host.py), Blake2b against
+// pinned against the independent Python statement (tests/transcript_ref.py, tests/test_host.py), Blake2b against
 // hashlib and RFC 7693's "abc" vector, the ChaCha block function against RFC 7539.
 #pragma once
 #include <stdint.h>
