@@ -22,8 +22,10 @@ ctx = typlonk_amd.Context(0)
 ctx.set_profiling(True)
 sh = ShardedMsm(ctx, n + 3, rank, world, dev)
 sh.generate_srs(fr_mont_limbs(2))
-if (sh.hi - sh.lo) >= (1 << 16) and os.environ.get("TABLES", "20") != "0":
-    ctx.srs_precompute(sh.sid, int(os.environ.get("TABLES", "20")))
+# TABLES: window bits of the fixed-base tables; "auto" = the library's choice by shard length, "0" = none
+tables = os.environ.get("TABLES", "auto")
+if (sh.hi - sh.lo) >= (1 << 16) and tables != "0":
+    ctx.srs_precompute(sh.sid, 0 if tables == "auto" else int(tables))
 full = synthetic_scalars(n, 0x5EED0000 + log_n, dev)
 for _ in range(10):
     sh.msm_local_devptr(full.data_ptr(), n)
@@ -35,7 +37,8 @@ for _ in range(reps):
     for k, v in ctx.profile():
         stages[k] = stages.get(k, 0.0) + v
 wall = (time.perf_counter() - t0) / reps * 1e3
-out = {"log_n": log_n, "world": world, "rank": rank, "local_terms": local_range(n, n + 3, world, rank)[1] - local_range(n, n + 3, world, rank)[0],
+out = {"log_n": log_n, "world": world, "rank": rank, "tables": tables, "lanes": os.environ.get("TYPLONK_MSM_LANES", "auto"),
+       "reduce": os.environ.get("TYPLONK_MSM_REDUCE", "rc2"), "local_terms": local_range(n, n + 3, world, rank)[1] - local_range(n, n + 3, world, rank)[0],
        "local_msm_wall_ms": round(wall, 4), "stages_ms": {k: round(v / reps, 4) for k, v in stages.items()}}
 ctx.set_profiling(False)
 for _ in range(10):
@@ -46,6 +49,9 @@ for _ in range(reps):
     xy, inf = sh.msm_local_devptr(full.data_ptr(), n)
 out["local_msm_wall_noprof_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
 
+if os.environ.get("NO_EXCHANGE") == "1":
+    print("SHARD " + json.dumps(out))
+    sys.exit(0)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -56,5 +62,5 @@ t0 = time.perf_counter()
 for _ in range(reps):
     allgather_fold(xy, inf, dev)
 out["exchange_fold_ms_one_rank_group"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
-print(json.dumps(out))
+print("SHARD " + json.dumps(out))
 dist.destroy_process_group()

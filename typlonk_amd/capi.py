@@ -294,8 +294,8 @@ class Context:
         self._chk(self.lib.typlonk_srs_download(self.h, sid, offset, count, _u64p(xy), _u8p(inf)))
         return xy, inf
 
-    def srs_precompute(self, sid: int, window_bits: int = 18):
-        """fixed-base window tables for this SRS (typlonk_srs_precompute)"""
+    def srs_precompute(self, sid: int, window_bits: int = 0):
+        """fixed-base window tables for this SRS (typlonk_srs_precompute); 0 = the library picks the window by length"""
         self._chk(self.lib.typlonk_srs_precompute(self.h, sid, window_bits))
 
     def srs_free(self, sid: int):

@@ -30,6 +30,7 @@ struct SrsEntry {
     uint32_t* d_points = nullptr;  // len * PT_WORDS u32 (96 B payload on a 128-B stride), identity = (0,0)
     size_t len = 0;
     uint32_t table_c = 0, table_T = 0;  // fixed-base tables 2^(c t) P_i at index t*len + i (typlonk_srs_precompute)
+    bool table_centred = false;         // table_T counts the windows of CENTRED scalars (launch.hpp, msm_windows)
     // typlonk_srs_set_shard: this entry holds bases [shard_first, shard_first + len) of a total_len-point SRS
     size_t shard_first = 0, total_len = 0;
     size_t total() const { return total_len ? total_len : len; }
@@ -136,6 +137,9 @@ struct typlonk_ctx {
     // bit 2 = first opening MSMs of round 3 submitted before the quotient
     int prover_overlap = 3;   // measured (profiles/r02_ab_prover_overlap.txt): bits 0-1 gain ~1 %, bit 2 loses ~1 %
     int msm_chunks = 0;            // TYPLONK_MSM_CHUNKS: chunks of a stand-alone MSM (0 = choose by length)
+    int msm_lanes = 0;             // TYPLONK_MSM_LANES: lanes per bucket of the accumulation (0 = choose by bucket load)
+    bool msm_rc4 = false;          // TYPLONK_MSM_REDUCE=rc4: always the four-launch row/column reduction (round-2 form)
+    bool msm_rc2_force = false;    // TYPLONK_MSM_REDUCE=rc2: the two-launch form for every bucket-set size
     int prover_rounds_active = 0;  // > 0 while a typlonk_prover_round* call is running (ProverRound)
     bool ntt_big_tiles = true;     // TYPLONK_NTT_BIG=0: always 1024-element tiles (three passes at 2^20)
     bool ntt_full_tables = true;   // TYPLONK_NTT_FULL_TABLES=0: compose twiddles / coset powers from two-level tables
@@ -662,7 +666,7 @@ void msm_shape(typlonk_ctx* ctx, size_t m, uint32_t* c_out, uint32_t* w_out) {
     if (c > 16) c = 16;
     if (ctx && ctx->msm_c_override) c = ctx->msm_c_override;
     *c_out = (uint32_t)c;
-    *w_out = (256 + c - 1) / c;
+    *w_out = msm_windows((uint32_t)c, false);
 }
 
 // Shape of the two-level (segmented) counting sort for an m-term MSM with c-bit windows: hb high bucket bits pick the
@@ -680,13 +684,14 @@ SegShape msm_seg_shape(size_t m, uint32_t c, uint32_t W, uint32_t nsets, bool ta
     uint32_t lgm = 0;
     while (((uint64_t)1 << lgm) < m) ++lgm;
     sh.ibits = tables ? std::max<uint32_t>(lgm, 1) : 23;
-    const int lb_max = tables ? std::min<int>(8, 32 - (int)sh.ibits - 5) : 8;
+    const int jbits = W > 16 ? 5 : 4;   // table mode: the window index travels in the level-1 entry
+    const int lb_max = tables ? std::min<int>(8, 32 - (int)sh.ibits - jbits - 1) : 8;
     int hb = std::max<int>((int)c - 1 - lb_max, tables ? 0 : (int)lgm - 13);
     sh.hb = std::max(0, std::min<int>(hb, (int)c - 1));
     sh.nseg = (uint64_t)nsets << sh.hb;
     sh.nblk = msm_segsort_blocks(m);
     sh.nmat = sh.nseg * sh.nblk;
-    sh.ok = m <= (1u << 23) && lb_max >= 1 && sh.nseg * 4 <= 64 * 1024 && sh.nmat < (1ull << 31) && (!tables || W <= 16) &&
+    sh.ok = m <= (1u << 23) && lb_max >= 1 && sh.nseg * 4 <= 64 * 1024 && sh.nmat < (1ull << 31) && (!tables || W <= 32) &&
             (uint64_t)W * m < (1ull << 31);
     return sh;
 }
@@ -729,9 +734,10 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         c = srs.table_c;
         W = srs.table_T;
     }
+    const bool centred = tables && srs.table_centred;
     const uint32_t B = 1u << (c - 1);
     // top window: t scalar bits -> 2^t digits, spread over 2^top_v virtual bucket copies
-    const uint32_t t_bits = 255 - c * (W - 1);
+    const uint32_t t_bits = (centred ? 254u : 255u) - c * (W - 1);
     const uint32_t top_v = (t_bits >= c - 1) ? 0u : (c - 1 - t_bits);
     // table mode: ONE bucket set for all windows -- the top window's digits d <= 2^t go to the shared
     // buckets d - 1 with their true weight (no virtual copies).  Balanced when t is large (c = 20: t = 15);
@@ -797,7 +803,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if ((rc = ensure(ctx, sb.cursor, nb * 4))) return rc;
         if ((rc = ensure(ctx, sb.blocksums, (size_t)scan_blocks * 4))) return rc;
         if ((rc = ensure(ctx, sb.order, nb * 4))) return rc;
-        if ((rc = ensure(ctx, sb.ohist, 514 * 4))) return rc;
+        if ((rc = ensure(ctx, sb.ohist, 516 * 4))) return rc;
         // heavy-bucket splitting: cap = entries one thread may sum; at most total/cap heavy buckets/tasks
         const uint32_t cap = (uint32_t)std::max<uint64_t>(512, 4 * ((total + nb_used - 1) / nb_used));
         const uint64_t max_tasks = total / cap + 2;
@@ -819,13 +825,13 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if (segsort) {
             if ((rc = ensure(ctx, sb.blk_hist, seg.nmat * 4))) return rc;
             if ((rc = ensure(ctx, sb.blk_base, (seg.nmat + 1) * 4))) return rc;
-            if ((rc = ensure(ctx, sb.blocksums, (size_t)((seg.nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks) * 4))) return rc;
+            if ((rc = ensure(ctx, sb.blocksums, (size_t)((seg.nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks + seg.nseg) * 4))) return rc;
             blocksums = (uint32_t*)sb.blocksums.p;
             StageTimer st(ctx, "msm_sort", ss);
             launch_msm_segsort(sc, (uint64_t)mk, c, W, digit_v, (uint32_t)seg.hb, seg.ibits, tables ? (uint32_t)srs.len : 0u,
                                tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums, keys,
                                counts, offsets, sorted, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p,
-                               (uint32_t*)sb.tasks.p, ss);
+                               (uint32_t*)sb.tasks.p, centred, ss);
         } else {
             {
                 StageTimer st(ctx, "msm_digits", ss);
@@ -851,9 +857,20 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             HIPCHK(hipStreamWaitEvent(s, ws.ev_sorted[k], 0));
         }
         {
+            // lanes per bucket: a short MSM over a small bucket set has few, long buckets -- spread each over L lanes so
+            // that the launch fills the chip (>= 2^17 threads = two wavefronts per SIMD), as long as a lane keeps >= 4 terms
+            uint32_t lanes = 1;
+            if (ctx->msm_lanes) {
+                lanes = (uint32_t)ctx->msm_lanes;
+            } else {
+                const uint64_t mean = total / nb_used;
+                while (lanes < 16 && nb_used * lanes < (1u << 17)) lanes *= 2;
+                while (lanes > 1 && mean / lanes < 4) lanes /= 2;
+            }
             StageTimer st(ctx, "msm_accum", s);
-            launch_msm_accum(pts, offsets, sorted, (const uint32_t*)sb.order.p, (uint32_t)nb_used, cap, /*init=*/k > 0, buckets, s);
-            launch_msm_heavy(pts, sorted, (const uint32_t*)sb.ohist.p, (const uint32_t*)sb.heavy.p,
+            launch_msm_accum(pts, offsets, sorted, (const uint32_t*)sb.order.p, (uint32_t)nb_used, cap, /*init=*/k > 0, lanes,
+                             buckets, s);
+            launch_msm_heavy(pts, sorted, (uint32_t*)sb.ohist.p, (const uint32_t*)sb.heavy.p,
                              (const uint32_t*)sb.tasks.p, (uint32_t*)sb.hpart.p, buckets, s);
         }
         if (nch > 1 && k + 2 < nch) HIPCHK(hipEventRecord(ws.ev_acc[k], s));
@@ -896,8 +913,13 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if ((rc = ensure(ctx, ws.rc_bits, (uint64_t)nsets * 2 * RC_NB * 64 * 192))) return rc;
         if ((rc = ensure(ctx, ws.rc_out, (uint64_t)nsets * 2 * RC_NB * 192))) return rc;
         StageTimer st(ctx, "msm_reduce", s);
-        launch_msm_rc_reduce(buckets, sh, (uint32_t*)ws.part_b.p, (uint32_t*)ws.part_a.p, (uint32_t*)ws.rc_sums.p,
-                             (uint32_t*)ws.rc_bits.p, (uint32_t*)ws.rc_out.p, s);
+        // two launches for small bucket sets, where the reduction is a latency chain; big sets are work-bound and the
+        // four-launch form wastes fewer lanes (2^19 buckets: 0.39 ms against 0.49, profiles/r03_shard_variants.jsonl)
+        if (!ctx->msm_rc4 && msm_rc2_ok(sh) && (ctx->msm_rc2_force || nb <= (1u << 17)))
+            launch_msm_rc2_reduce(buckets, sh, (uint32_t*)ws.part_b.p, (uint32_t*)ws.part_a.p, (uint32_t*)ws.rc_out.p, s);
+        else
+            launch_msm_rc_reduce(buckets, sh, (uint32_t*)ws.part_b.p, (uint32_t*)ws.part_a.p, (uint32_t*)ws.rc_sums.p,
+                                 (uint32_t*)ws.rc_bits.p, (uint32_t*)ws.rc_out.p, s);
         if (nsets > 1) {
             // plain MSM: per-set powers of two on the device, the host keeps its Horner over the windows
             uint32_t* set_sums = (uint32_t*)ws.part_a.p;  // the column partials are consumed by now
@@ -1119,7 +1141,15 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         if (c >= 4 && c <= 20) ctx->msm_c_override = c;
     }
     if (const char* e = getenv("TYPLONK_MSM_SORT")) ctx->msm_legacy_sort = (strcmp(e, "atomic") == 0);
-    if (const char* e = getenv("TYPLONK_MSM_REDUCE")) ctx->msm_tree_reduce = (strcmp(e, "running") == 0);
+    if (const char* e = getenv("TYPLONK_MSM_REDUCE")) {
+        ctx->msm_tree_reduce = (strcmp(e, "running") == 0);
+        ctx->msm_rc4 = (strcmp(e, "rc4") == 0);
+        ctx->msm_rc2_force = (strcmp(e, "rc2") == 0);
+    }
+    if (const char* e = getenv("TYPLONK_MSM_LANES")) {
+        const int l = atoi(e);
+        if (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) ctx->msm_lanes = l;
+    }
     if (const char* e = getenv("TYPLONK_MSM_INFLIGHT")) ctx->msm_inflight = atoi(e);
     if (const char* e = getenv("TYPLONK_PROVER_OVERLAP")) ctx->prover_overlap = atoi(e);
     if (const char* e = getenv("TYPLONK_MSM_CHUNKS")) ctx->msm_chunks = std::max(0, std::min(atoi(e), MSM_MAX_CHUNKS));
@@ -1262,12 +1292,15 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     auto it = ctx->srs.find(srs_id);
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
-    if (window_bits < 16 || window_bits > 20) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "window_bits must be 16..20");
+    if (window_bits == 0) window_bits = it->second.len < (1u << 18) ? 17 : 20;   // measured best: DESIGN.md section 6
+    if (window_bits < 14 || window_bits > 20) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "window_bits must be 0 (auto) or 14..20");
     SrsEntry& e = it->second;
     if (e.table_T) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "tables already built for this SRS");
     if (e.len == 0 || e.len > (1u << 23)) return fail(ctx, TYPLONK_ERR_LENGTH, "tables need 1 <= len <= 2^23");
     HIPCHK(hipSetDevice(ctx->device));
-    const uint32_t T = (256 + window_bits - 1) / window_bits;
+    // centred scalars (|k| < 2^254) save a window -- and a table -- for c = 17 (15 instead of 16) and c = 15
+    const bool centred = msm_windows(window_bits, true) < msm_windows(window_bits, false);
+    const uint32_t T = msm_windows(window_bits, centred);
     // An MSM whose length has no table-mode sort shape (m > 2^22 with 20-bit windows: 23 index bits leave too few low
     // bucket bits for the LDS level of the sort) simply takes the plain path over table 0, which IS the SRS
     // (msm_enqueue) -- a set-up call that is supposed to be speed-only never turns a valid MSM into an error.  Only a
@@ -1287,6 +1320,7 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     e.d_points = big;
     e.table_c = window_bits;
     e.table_T = T;
+    e.table_centred = centred;
     return TYPLONK_OK;
 }
 

@@ -82,16 +82,25 @@ uint32_t msm_segsort_blocks(uint64_t m);  // workgroups of the level-1 passes fo
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
-                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, hipStream_t s);
+                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, bool centred, hipStream_t s);
+// windows of the signed c-bit digit decomposition.  Scalars are canonical (< r < 2^255): the top window holds
+// t = bits - c (W0 - 1) bits, W0 = ceil(bits / c), and a digit <= 2^t cannot exceed 2^(c-1) (no carry out of it) unless
+// t = c.  Centred scalars (|k| <= (r - 1)/2 < 2^254) have one bit less: c = 17 -> 15 windows instead of 16.
+TY_HD uint32_t msm_windows(uint32_t c, bool centred) {
+    const uint32_t bits = centred ? 254u : 255u;
+    const uint32_t w0 = (bits + c - 1) / c;
+    return w0 + ((bits - c * (w0 - 1)) == c ? 1u : 0u);
+}
 void launch_srs_tables(uint32_t* pts, uint64_t len, uint32_t c, uint32_t T, hipStream_t s);
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
                          uint32_t* order, uint32_t* heavy, uint32_t* tasks, bool hist_done, hipStream_t s);
-void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist514, const uint32_t* heavy,
+void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, uint32_t* hist516, const uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s);
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
                         hipStream_t s);
+// lanes = 1, 2, 4, 8, 16: lanes per bucket (msm_accum_kernel / msm_accum_ml_kernel<L>)
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
-                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t* buckets, hipStream_t s);
+                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t lanes, uint32_t* buckets, hipStream_t s);
 void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
                        uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s);
 void launch_msm_fold(const uint32_t* in, uint32_t total, uint32_t group, uint32_t* out, hipStream_t s);
@@ -133,6 +142,10 @@ TY_HD uint32_t rc_weight(const RcShape& sh, uint32_t set, uint32_t kind, uint32_
 }
 void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* pb, uint32_t* pa, uint32_t* sums,
                           uint32_t* bitsum, uint32_t* out, hipStream_t s);
+// the same bit planes in two launches (msm_reduce.hip); needs cl, ch >= 6; prow, pcol: nsets << (c1 - 6) points each
+bool msm_rc2_ok(const RcShape& sh);
+void launch_msm_rc2_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* prow, uint32_t* pcol, uint32_t* out,
+                           hipStream_t s);
 void launch_msm_rc_combine(const uint32_t* planes, const RcShape& sh, uint32_t* set_sums, hipStream_t s);
 void launch_srs_generate(const Fr& s, uint64_t start, uint64_t n, uint32_t* pts, hipStream_t st);
 

@@ -60,12 +60,62 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_kernel(const uint32
     st_xyzz(buckets, g, acc);
 }
 
-// tasks of heavy buckets, one per thread, grid-strided (the task count lives on the device)
+// The same with L = 2, 4, 8 or 16 lanes per bucket (KzgScheme::evaluate_in_s of a SHORT vector -- an 8-way shard of
+// a 2^20-term commitment, kzg/src/lib.rs:41-54 -- with small windows: 2^14..2^16 buckets of 30..130 entries each).
+// One thread per bucket would leave three quarters of the chip idle and every thread with a long dependent chain;
+// here the L lanes of a group stride over the bucket's entries and a wavefront butterfly (butterfly_add: the two
+// lanes of a pair share one XYZZ addition) folds the L partial sums.  Schedule, cap and `init` as above.
+template <int L>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_ml_kernel(const uint32_t* __restrict__ points,
+                                                                       const uint32_t* __restrict__ offsets,
+                                                                       const uint32_t* __restrict__ sorted,
+                                                                       const uint32_t* __restrict__ order,
+                                                                       uint32_t nbuckets, uint32_t cap, uint32_t init,
+                                                                       uint32_t* buckets) {
+    const uint32_t t = blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    const uint32_t slot = t / L, lane = t % L;
+    // every lane of the wavefront takes part in the butterfly: lanes past the last bucket carry the identity
+    uint32_t g = 0, start = 0, end = 0;
+    if (slot < nbuckets) {
+        g = order[slot];
+        start = offsets[g];
+        end = min(offsets[g + 1], start + cap);
+    }
+    const bool skip = slot >= nbuckets || (init && start >= end);   // nothing to add: the stored bucket stays
+    G1Xyzz acc = (init && !skip && lane == 0) ? ld_xyzz(buckets, g) : G1Xyzz::inf();
+    uint32_t pl_next = 0;
+    PackedPoint pk_next;
+    uint32_t pos = start + lane;
+    if (pos < end) {
+        pl_next = sorted[pos];
+        pk_next = ld_packed(points, pl_next & 0x7fffffffu);
+    }
+    for (; pos < end; pos += L) {
+        const uint32_t pl = pl_next;
+        const PackedPoint pk = pk_next;
+        if (pos + L < end) {
+            pl_next = sorted[pos + L];
+            pk_next = ld_packed(points, pl_next & 0x7fffffffu);
+        }
+        g1_madd(acc, unpack_point(pk), (pl >> 31) != 0);
+    }
+#pragma unroll 1
+    for (int mask = 1; mask < L; mask <<= 1) acc = butterfly_add(acc, mask);
+    if (!skip && lane == 0) st_xyzz(buckets, g, acc);
+}
+
+// Heavy buckets (adversarial scalar sets only): tasks one per thread, grid-strided (the task count lives on the
+// device), then the LAST workgroup to finish adds every heavy bucket's task partials into the bucket -- one launch
+// for both steps, and with no task at all (every ordinary MSM) the launch returns at once.
+// hist516: [512] heavy buckets, [513] tasks, [514] workgroups done (left at zero again).
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_kernel(const uint32_t* __restrict__ points,
-                                                                    const uint32_t* __restrict__ sorted,
-                                                                    const uint32_t* __restrict__ hist514,
-                                                                    const uint32_t* __restrict__ tasks, uint32_t* partial) {
-    const uint32_t ntasks = hist514[513];
+                                                                    const uint32_t* __restrict__ sorted, uint32_t* hist516,
+                                                                    const uint32_t* __restrict__ heavy,
+                                                                    const uint32_t* __restrict__ tasks, uint32_t* partial,
+                                                                    uint32_t* buckets) {
+    __shared__ uint32_t is_last;
+    const uint32_t ntasks = hist516[513];
+    if (ntasks == 0) return;
     for (uint32_t t = blockIdx.x * MSM_ACC_THREADS + threadIdx.x; t < ntasks; t += gridDim.x * MSM_ACC_THREADS) {
         G1Xyzz acc = G1Xyzz::inf();
         for (uint32_t pos = tasks[2 * t]; pos < tasks[2 * t + 1]; ++pos) {
@@ -74,29 +124,39 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_kernel(const uint32
         }
         st_xyzz(partial, t, acc);
     }
-}
-// one thread per heavy bucket: bucket += sum of its task partials
-__global__ __launch_bounds__(64) void msm_heavy_combine_kernel(const uint32_t* __restrict__ hist514,
-                                                               const uint32_t* __restrict__ heavy,
-                                                               const uint32_t* __restrict__ partial, uint32_t* buckets) {
-    const uint32_t nheavy = hist514[512];
-    for (uint32_t h = blockIdx.x * 64 + threadIdx.x; h < nheavy; h += gridDim.x * 64) {
+    __threadfence();  // this workgroup's partials are visible device-wide before it counts itself done
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&hist516[514], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();  // ... and the last one sees everybody's
+    const uint32_t nheavy = hist516[512];
+    for (uint32_t h = threadIdx.x; h < nheavy; h += MSM_ACC_THREADS) {
         const uint32_t b = heavy[3 * h], t0 = heavy[3 * h + 1], k = heavy[3 * h + 2];
         G1Xyzz acc = ld_xyzz(buckets, b);
         for (uint32_t t = 0; t < k; ++t) acc = g1_add(acc, ld_xyzz(partial, t0 + t));
         st_xyzz(buckets, b, acc);
     }
+    if (threadIdx.x == 0) hist516[514] = 0;
 }
 
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
-                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t* buckets, hipStream_t s) {
-    hipLaunchKernelGGL(msm_accum_kernel, dim3((nbuckets + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), dim3(MSM_ACC_THREADS), 0,
-                       s, points, offsets, sorted, order, nbuckets, cap, init ? 1u : 0u, buckets);
+                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t lanes, uint32_t* buckets, hipStream_t s) {
+    const uint64_t threads = (uint64_t)nbuckets * (lanes ? lanes : 1u);
+    const dim3 grid((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), block(MSM_ACC_THREADS);
+    const uint32_t in = init ? 1u : 0u;
+    switch (lanes) {
+        case 2: hipLaunchKernelGGL(msm_accum_ml_kernel<2>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
+        case 4: hipLaunchKernelGGL(msm_accum_ml_kernel<4>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
+        case 8: hipLaunchKernelGGL(msm_accum_ml_kernel<8>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
+        case 16: hipLaunchKernelGGL(msm_accum_ml_kernel<16>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
+        default: hipLaunchKernelGGL(msm_accum_kernel, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets);
+    }
 }
-void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist514, const uint32_t* heavy,
+void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, uint32_t* hist516, const uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s) {
-    hipLaunchKernelGGL(msm_heavy_kernel, dim3(256), dim3(MSM_ACC_THREADS), 0, s, points, sorted, hist514, tasks, partial);
-    hipLaunchKernelGGL(msm_heavy_combine_kernel, dim3(64), dim3(64), 0, s, hist514, heavy, partial, buckets);
+    hipLaunchKernelGGL(msm_heavy_kernel, dim3(256), dim3(MSM_ACC_THREADS), 0, s, points, sorted, hist516, heavy, tasks, partial,
+                       buckets);
 }
 
 }  // namespace ty

@@ -64,4 +64,92 @@ __device__ __forceinline__ void st_xyzz(uint32_t* b, uint64_t idx, const G1Xyzz&
     st_fq(p + 36, r.zzz);
 }
 
+// ---- wavefront exchange of whole points (bucket reduction, multi-lane bucket accumulation) ----------------------
+__device__ __forceinline__ G1Xyzz shfl_xor_point(const G1Xyzz& p, int mask) {
+    G1Xyzz r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        r.x.v[i] = __shfl_xor(p.x.v[i], mask);
+        r.y.v[i] = __shfl_xor(p.y.v[i], mask);
+        r.zz.v[i] = __shfl_xor(p.zz.v[i], mask);
+        r.zzz.v[i] = __shfl_xor(p.zzz.v[i], mask);
+    }
+    return r;
+}
+
+__device__ __forceinline__ Fq30 shfl_xor_fq(const Fq30& a, int mask) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.v[i] = __shfl_xor(a.v[i], mask);
+    return r;
+}
+__device__ __forceinline__ Fq30 fq_sel(bool c, const Fq30& a, const Fq30& b) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+
+// v <- v + (value of lane ^ mask), on both lanes of every pair: the butterfly step of the reductions.
+// The two lanes of a pair split the 12M + 2S of add-2008-s between them (7 multiplication times instead of 14):
+// with a = the lower lane's point and b = the upper lane's,
+//   step 1  every lane: own.x * other.zz (U1 on the lower lane, U2 on the upper), own.y * other.zzz (S1 / S2);
+//           lower: a.zz * b.zz, upper: a.zzz * b.zzz                                  -> exchange
+//   step 2  lower: PP = P^2, upper: R^2  (P = U2 - U1, R = S2 - S1)                   -> exchange
+//   step 3  lower: PPP = P * PP, upper: Q = U1 * PP                                   -> exchange
+//   step 4  lower: R * (Q - X3) and ZZ12 * PP, upper: S1 * PPP and ZZZ12 * PPP        -> exchange
+// Bounds are those of g1_add (g1.hpp).  An identity operand selects the other point at the end; equal points are
+// doubled and opposite points give the identity there too (wave-uniform branch, taken only when some pair needs it).
+__device__ __forceinline__ G1Xyzz butterfly_add(const G1Xyzz& v, int mask) {
+    const bool lower = (threadIdx.x & (uint32_t)mask) == 0;
+    const bool v_inf = v.is_inf();
+    const bool o_inf = __shfl_xor((int)v_inf, mask) != 0;
+    // Only the partner's ZZ and ZZZ are fetched up front (its X and Y are needed only when this lane holds the identity,
+    // below): 26 registers fewer alive through the four steps -- what keeps the multi-lane accumulation kernel at two
+    // wavefronts per SIMD.
+    Fq30 u1, s1, pd, rd, zz_own;
+    {
+        const Fq30 ozz = shfl_xor_fq(v.zz, mask), ozzz = shfl_xor_fq(v.zzz, mask);
+        // step 1
+        const Fq30 u_own = fq30_mul(v.x, ozz);                               // < 1.01
+        const Fq30 s_own = fq30_mul(v.y, ozzz);                              // < 1.01
+        zz_own = fq30_mul(fq_sel(lower, v.zz, v.zzz), fq_sel(lower, ozz, ozzz));   // ZZ12 (lower) | ZZZ12 (upper)  < 1.01
+        const Fq30 u_oth = shfl_xor_fq(u_own, mask), s_oth = shfl_xor_fq(s_own, mask);
+        u1 = fq_sel(lower, u_own, u_oth);
+        s1 = fq_sel(lower, s_own, s_oth);
+        pd = fq30_sub_lazy<2>(fq_sel(lower, u_oth, u_own), u1);              // U2 - U1  < 3.1
+        rd = fq30_sub_lazy<2>(fq_sel(lower, s_oth, s_own), s1);              // S2 - S1  < 3.1
+    }
+    // step 2
+    const Fq30 sq_own = fq30_sqr(fq_sel(lower, pd, rd));                     // PP | RR  < 1.02
+    const Fq30 sq_oth = shfl_xor_fq(sq_own, mask);
+    const Fq30 pp = fq_sel(lower, sq_own, sq_oth), rr = fq_sel(lower, sq_oth, sq_own);
+    // equal or opposite points (P = 0): the formulas below do not apply to that pair; settled at the end
+    const bool exc = !v_inf && !o_inf && fq30_is_zero_mod(pp);
+    const bool same = fq30_is_zero_mod(rr);                                  // ... and R = 0: the same point
+    // step 3
+    const Fq30 m3_own = fq30_mul(fq_sel(lower, pd, u1), pp);                 // PPP | Q  < 1.01
+    const Fq30 m3_oth = shfl_xor_fq(m3_own, mask);
+    const Fq30 ppp = fq_sel(lower, m3_own, m3_oth), q = fq_sel(lower, m3_oth, m3_own);
+    G1Xyzz out;
+    out.x = fq30_sub2_lazy<4>(rr, ppp, fq30_mulk_lazy<2>(q));               // < 5.1
+    const Fq30 t = fq30_sub_lazy<6>(q, out.x);                               // < 7.1
+    // step 4: each lane multiplies its own ZZ12 / ZZZ12 (no exchange needed for those)
+    const Fq30 y_own = fq30_mul(fq_sel(lower, rd, s1), fq_sel(lower, t, ppp));   // R*T | S1*PPP
+    const Fq30 z_own = fq30_mul(zz_own, fq_sel(lower, pp, ppp));                  // ZZ3 | ZZZ3  < 1.01
+    const Fq30 y_oth = shfl_xor_fq(y_own, mask), z_oth = shfl_xor_fq(z_own, mask);
+    out.y = fq30_sub_lazy<2>(fq_sel(lower, y_own, y_oth), fq_sel(lower, y_oth, y_own));   // R*T - S1*PPP  < 3.1
+    out.zz = fq_sel(lower, z_own, z_oth);
+    out.zzz = fq_sel(lower, z_oth, z_own);
+    // An identity operand selects the other point (the formulas above then ran on zeros, harmlessly); equal points
+    // double, opposite points cancel -- both lanes of such a pair hold the same point, so each settles it alone.
+    if (__any(v_inf || o_inf || exc)) {
+        const G1Xyzz o = shfl_xor_point(v, mask);
+        if (exc) out = same ? g1_dbl(v) : G1Xyzz::inf();
+        else if (v_inf) out = o;
+        else if (o_inf) out = v;
+    }
+    return out;
+}
+
 }  // namespace ty

@@ -4,81 +4,6 @@
 
 namespace ty {
 
-__device__ __forceinline__ G1Xyzz shfl_xor_point(const G1Xyzz& p, int mask) {
-    G1Xyzz r;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        r.x.v[i] = __shfl_xor(p.x.v[i], mask);
-        r.y.v[i] = __shfl_xor(p.y.v[i], mask);
-        r.zz.v[i] = __shfl_xor(p.zz.v[i], mask);
-        r.zzz.v[i] = __shfl_xor(p.zzz.v[i], mask);
-    }
-    return r;
-}
-
-__device__ __forceinline__ Fq30 shfl_xor_fq(const Fq30& a, int mask) {
-    Fq30 r;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) r.v[i] = __shfl_xor(a.v[i], mask);
-    return r;
-}
-__device__ __forceinline__ Fq30 fq_sel(bool c, const Fq30& a, const Fq30& b) {
-    Fq30 r;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) r.v[i] = c ? a.v[i] : b.v[i];
-    return r;
-}
-
-// v <- v + (value of lane ^ mask), on both lanes of every pair: the butterfly step of the reductions.
-// The two lanes of a pair split the 12M + 2S of add-2008-s between them (7 multiplication times instead of 14):
-// with a = the lower lane's point and b = the upper lane's,
-//   step 1  every lane: own.x * other.zz (U1 on the lower lane, U2 on the upper), own.y * other.zzz (S1 / S2);
-//           lower: a.zz * b.zz, upper: a.zzz * b.zzz                                  -> exchange
-//   step 2  lower: PP = P^2, upper: R^2  (P = U2 - U1, R = S2 - S1)                   -> exchange
-//   step 3  lower: PPP = P * PP, upper: Q = U1 * PP                                   -> exchange
-//   step 4  lower: R * (Q - X3) and ZZ12 * PP, upper: S1 * PPP and ZZZ12 * PPP        -> exchange
-// Bounds are those of g1_add (g1.hpp).  An identity operand selects the other point at the end.  Equal or opposite
-// points are rare: if ANY pair of the wavefront meets them, the whole wavefront takes the one-lane g1_add instead.
-__device__ __forceinline__ G1Xyzz butterfly_add(const G1Xyzz& v, int mask) {
-    const G1Xyzz o = shfl_xor_point(v, mask);
-    const bool lower = (threadIdx.x & (uint32_t)mask) == 0;
-    // step 1
-    const Fq30 u_own = fq30_mul(v.x, o.zz);                              // < 1.01
-    const Fq30 s_own = fq30_mul(v.y, o.zzz);                             // < 1.01
-    const Fq30 zz_own = fq30_mul(fq_sel(lower, v.zz, v.zzz), fq_sel(lower, o.zz, o.zzz));   // ZZ12 | ZZZ12  < 1.01
-    const Fq30 u_oth = shfl_xor_fq(u_own, mask), s_oth = shfl_xor_fq(s_own, mask), zz_oth = shfl_xor_fq(zz_own, mask);
-    const Fq30 u1 = fq_sel(lower, u_own, u_oth), u2 = fq_sel(lower, u_oth, u_own);
-    const Fq30 s1 = fq_sel(lower, s_own, s_oth), s2 = fq_sel(lower, s_oth, s_own);
-    const Fq30 zz12 = fq_sel(lower, zz_own, zz_oth), zzz12 = fq_sel(lower, zz_oth, zz_own);
-    const Fq30 pd = fq30_sub_lazy<2>(u2, u1);                            // < 3.1
-    const Fq30 rd = fq30_sub_lazy<2>(s2, s1);                            // < 3.1
-    // step 2
-    const Fq30 sq_own = fq30_sqr(fq_sel(lower, pd, rd));                 // PP | RR  < 1.02
-    const Fq30 sq_oth = shfl_xor_fq(sq_own, mask);
-    const Fq30 pp = fq_sel(lower, sq_own, sq_oth), rr = fq_sel(lower, sq_oth, sq_own);
-    // an identity operand just selects the other point below (the formulas then run on zeros, harmlessly);
-    // equal or opposite points need the doubling / identity branches of g1_add
-    const bool v_inf = v.is_inf(), o_inf = o.is_inf();
-    if (__any(!v_inf && !o_inf && fq30_is_zero_mod(pp))) return g1_add(v, o);
-    // step 3
-    const Fq30 m3_own = fq30_mul(fq_sel(lower, pd, u1), pp);             // PPP | Q  < 1.01
-    const Fq30 m3_oth = shfl_xor_fq(m3_own, mask);
-    const Fq30 ppp = fq_sel(lower, m3_own, m3_oth), q = fq_sel(lower, m3_oth, m3_own);
-    G1Xyzz out;
-    out.x = fq30_sub2_lazy<4>(rr, ppp, fq30_mulk_lazy<2>(q));           // < 5.1
-    const Fq30 t = fq30_sub_lazy<6>(q, out.x);                           // < 7.1
-    // step 4
-    const Fq30 y_own = fq30_mul(fq_sel(lower, rd, s1), fq_sel(lower, t, ppp));       // R*T | S1*PPP
-    const Fq30 z_own = fq30_mul(fq_sel(lower, zz12, zzz12), fq_sel(lower, pp, ppp));  // ZZ3 | ZZZ3  < 1.01
-    const Fq30 y_oth = shfl_xor_fq(y_own, mask), z_oth = shfl_xor_fq(z_own, mask);
-    out.y = fq30_sub_lazy<2>(fq_sel(lower, y_own, y_oth), fq_sel(lower, y_oth, y_own));   // R*T - S1*PPP  < 3.1
-    out.zz = fq_sel(lower, z_own, z_oth);
-    out.zzz = fq_sel(lower, z_oth, z_own);
-    if (v_inf) return o;
-    if (o_inf) return v;
-    return out;
-}
-
 // Thread t owns buckets [t*L, (t+1)*L) of the flat (window-major) bucket array, L = min(8, B).
 // node value = sum_l w(s*L + l) * bucket[l]   with s = t mod (B/L) and bucket weight
 // w(k) = (k >> v) + 1, v = 0 except in the top window (v = top_v, see msm_digits_kernel);
@@ -228,6 +153,106 @@ __global__ __launch_bounds__(64) void msm_rc_final_kernel(const uint32_t* __rest
     if (threadIdx.x < count) v = ld_xyzz(bitsum, (uint64_t)blockIdx.x * 64 + threadIdx.x);
     for (uint32_t mask = 1; mask < count; mask <<= 1) v = butterfly_add(v, (int)mask);
     if (threadIdx.x == 0) st_xyzz(out, blockIdx.x, v);
+}
+
+// ---- the same reduction in two launches (bucket sets of >= 2^12 buckets) ---------------------------------------------
+// The four kernels above are a chain of ~24 dependent additions behind four launches; a short MSM (an 8-way shard)
+// spends more time in that chain than in its bucket additions.  Here
+//   1. msm_rc2_sums_kernel    one wavefront per run of 64 * 2^s buckets of a row (row role) or of a column (column
+//                             role): every lane sums 2^s buckets, a 6-step butterfly (butterfly_add: 7 multiplication
+//                             times per step) folds the 64 lanes -> P partials per row / column.  s is chosen so that
+//                             the launch has ~1024 wavefronts, one per SIMD (2^16 buckets: s = 1, 14 + 42
+//                             multiplication times per wavefront);
+//   2. msm_rc2_planes_kernel  one workgroup per (set, kind, weight bit): the partials of the items whose weight has
+//                             that bit set are butterfly-summed per wavefront, then across the wavefronts through LDS.
+// Same bit planes out as msm_rc_final_kernel (the host finish does not change).
+__global__ __launch_bounds__(64) void msm_rc2_sums_kernel(const uint32_t* __restrict__ buckets, RcShape sh, uint32_t sr,
+                                                          uint32_t sc, uint32_t nwave_row, uint32_t* prow, uint32_t* pcol) {
+    G1Xyzz v;
+    if (blockIdx.x < nwave_row) {
+        const uint64_t base = ((uint64_t)blockIdx.x * 64 + threadIdx.x) << sr;   // a run never leaves its row: 64 * 2^sr | C
+        v = ld_xyzz(buckets, base);
+        for (uint32_t i = 1; i < (1u << sr); ++i) v = g1_add(v, ld_xyzz(buckets, base + i));
+    } else {
+        const uint32_t u = blockIdx.x - nwave_row;
+        const uint32_t lpc = sh.ch - 6 - sc;                                      // log2 partials per column
+        const uint32_t rchunk = u & ((1u << lpc) - 1), col = u >> lpc;            // col = set << cl | lo
+        const uint32_t set = col >> sh.cl, lo = col & ((1u << sh.cl) - 1);
+        const uint32_t row0 = ((rchunk * 64 + threadIdx.x) << sc);
+        const uint64_t first = ((uint64_t)set << sh.c1) + ((uint64_t)row0 << sh.cl) + lo;
+        v = ld_xyzz(buckets, first);
+        for (uint32_t i = 1; i < (1u << sc); ++i) v = g1_add(v, ld_xyzz(buckets, first + ((uint64_t)i << sh.cl)));
+    }
+#pragma unroll 1
+    for (int mask = 1; mask < 64; mask <<= 1) v = butterfly_add(v, mask);
+    if (threadIdx.x == 0) {
+        if (blockIdx.x < nwave_row) st_xyzz(prow, blockIdx.x, v);
+        else st_xyzz(pcol, blockIdx.x - nwave_row, v);
+    }
+}
+
+constexpr int RC2_THREADS = 256;  // 4 wavefronts, one per SIMD: two per SIMD double every butterfly step's latency (measured
+                                  // 115 us with 512 threads on 512 partials)
+__global__ __launch_bounds__(RC2_THREADS) void msm_rc2_planes_kernel(const uint32_t* __restrict__ prow,
+                                                                     const uint32_t* __restrict__ pcol, RcShape sh,
+                                                                     uint32_t lpr, uint32_t lpc, uint32_t* out) {
+    __shared__ uint32_t xch[RC2_THREADS / 64][52];
+    const uint32_t bit = blockIdx.x % RC_NB, kind = (blockIdx.x / RC_NB) & 1u, set = blockIdx.x / (2 * RC_NB);
+    uint32_t nbr, nbc, shift;
+    rc_bits(sh, set, &nbr, &nbc, &shift);
+    if (bit >= (kind ? nbc : nbr)) return;
+    const uint32_t litems = kind ? sh.cl : sh.ch, lp = kind ? lpc : lpr;
+    const uint32_t* src = kind ? pcol : prow;
+    const uint32_t np = 1u << (litems + lp);
+    G1Xyzz v = G1Xyzz::inf();
+    for (uint32_t idx = threadIdx.x; idx < np; idx += blockDim.x) {
+        const uint32_t item = idx >> lp;
+        if ((rc_weight(sh, set, kind, item) >> bit) & 1u) v = g1_add(v, ld_xyzz(src, ((uint64_t)set << (litems + lp)) + idx));
+    }
+#pragma unroll 1
+    for (int mask = 1; mask < 64; mask <<= 1) v = butterfly_add(v, mask);
+    const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            xch[wave][i] = v.x.v[i];
+            xch[wave][13 + i] = v.y.v[i];
+            xch[wave][26 + i] = v.zz.v[i];
+            xch[wave][39 + i] = v.zzz.v[i];
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    v = G1Xyzz::inf();
+    if (threadIdx.x < nwaves) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            v.x.v[i] = xch[threadIdx.x][i];
+            v.y.v[i] = xch[threadIdx.x][13 + i];
+            v.zz.v[i] = xch[threadIdx.x][26 + i];
+            v.zzz.v[i] = xch[threadIdx.x][39 + i];
+        }
+    }
+#pragma unroll 1
+    for (int mask = 1; mask < (int)nwaves; mask <<= 1) v = butterfly_add(v, mask);
+    if (threadIdx.x == 0) st_xyzz(out, blockIdx.x, v);
+}
+
+bool msm_rc2_ok(const RcShape& sh) { return sh.cl >= 6 && sh.ch >= 6; }
+// scratch: prow holds nsets << (c1 - 6 - sr) partials, pcol nsets << (c1 - 6 - sc); both <= nsets << (c1 - 6)
+void launch_msm_rc2_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* prow, uint32_t* pcol, uint32_t* out,
+                           hipStream_t s) {
+    uint32_t lnb = sh.c1;
+    for (uint32_t n = sh.nsets; n > 1; n >>= 1) ++lnb;        // ~log2 of all buckets
+    const uint32_t want = lnb > 15 ? lnb - 15 : 0;            // ~1024 wavefronts in the first launch
+    const uint32_t sr = want < sh.cl - 6 ? want : sh.cl - 6, sc = want < sh.ch - 6 ? want : sh.ch - 6;
+    const uint32_t nwave_row = sh.nsets << (sh.c1 - 6 - sr), nwave_col = sh.nsets << (sh.c1 - 6 - sc);
+    hipLaunchKernelGGL(msm_rc2_sums_kernel, dim3(nwave_row + nwave_col), dim3(64), 0, s, buckets, sh, sr, sc, nwave_row, prow,
+                       pcol);
+    const uint32_t lpr = sh.cl - 6 - sr, lpc = sh.ch - 6 - sc;
+    const uint32_t np = 1u << ((sh.ch + lpr) > (sh.cl + lpc) ? (sh.ch + lpr) : (sh.cl + lpc));
+    const uint32_t threads = np < 64 ? 64u : (np > (uint32_t)RC2_THREADS ? (uint32_t)RC2_THREADS : np);
+    hipLaunchKernelGGL(msm_rc2_planes_kernel, dim3(sh.nsets * 2 * RC_NB), dim3(threads), 0, s, prow, pcol, sh, lpr, lpc, out);
 }
 
 // Plain (multi-set) MSMs: one wavefront per set applies the powers of two -- lane (kind, b) doubles its bit

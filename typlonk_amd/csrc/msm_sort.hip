@@ -1,6 +1,7 @@
 // MSM staging kernels: infinity marking, scalar -> signed window digits + histogram, exclusive scan,
 // counting-sort scatter.  See msm_common.hpp for the overall MSM structure.
 #include <stdlib.h>
+#include <string.h>
 
 #include "launch.hpp"
 #include "msm_common.hpp"
@@ -175,16 +176,22 @@ inline uint32_t msm_seg1_threads() {
     }();
     return t;
 }
-inline uint32_t msm_seg1_per_thread() {
-    static const uint32_t t = [] {
+// scalars per thread of the level-1 passes: 8 from 2^20 terms on; a short MSM (an index shard) gets fewer, so that its
+// level-1 launches still have 512 workgroups -- at 2^17 terms 8 per thread is 64 workgroups and 34 + 39 us for the
+// histogram and the scatter, 1 per thread 512 workgroups (profiles/r03_shard_timeline.txt)
+inline uint32_t msm_seg1_per_thread(uint64_t m) {
+    static const uint32_t forced = [] {
         const char* e = getenv("TYPLONK_SEG1_PER_THREAD");
-        const int v = e ? atoi(e) : 8;
-        return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 16 || v == 32) ? v : 8);
+        const int v = e ? atoi(e) : 0;
+        return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0);
     }();
-    return t;
+    if (forced) return forced;
+    uint32_t per = 8;
+    while (per > 1 && (uint64_t)per * msm_seg1_threads() * 512 > m) per >>= 1;
+    return per;
 }
 inline uint32_t msm_chunk_for(uint64_t m) {
-    uint32_t chunk = msm_seg1_per_thread() * msm_seg1_threads();
+    uint32_t chunk = msm_seg1_per_thread(m) * msm_seg1_threads();
     while (((uint64_t)chunk << 9) < m) chunk <<= 1;  // at most 512 workgroups
     return chunk;
 }
@@ -196,6 +203,9 @@ struct MsmShape {
     // fixed-base table mode (tlen != 0): base (j, i) lives at gather index j * tlen + i and all windows
     // share one bucket set (nsets = 1)
     uint32_t tlen, nsets;
+    // centred scalars: k > (r - 1)/2 is replaced by r - k with every digit's sign flipped, so |k| < 2^254 and
+    // c = 17 needs 15 windows instead of 16, c = 15 17 instead of 18 (launch.hpp, msm_windows)
+    uint32_t centred;
 };
 
 __device__ __forceinline__ uint32_t msm_seg_of(const MsmShape& sh, uint32_t j, uint32_t b) {
@@ -225,15 +235,28 @@ __device__ __forceinline__ void msm_for_each_digit(const uint32_t (&v)[8], const
     }
 }
 
-__device__ __forceinline__ void msm_load_canon(const Fr* scalars, uint64_t i, uint32_t (&out)[8]) {
+// canonical value of scalar i; centred != 0: min(k, r - k) instead, returns 1 when it is r - k (signs flip)
+__device__ __forceinline__ uint32_t msm_load_canon(const Fr* scalars, uint64_t i, uint32_t centred, uint32_t (&out)[8]) {
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + i);
     const uint4 a = sp[0], b = sp[1];
     Fr s;
     s.v[0] = a.x; s.v[1] = a.y; s.v[2] = a.z; s.v[3] = a.w;
     s.v[4] = b.x; s.v[5] = b.y; s.v[6] = b.z; s.v[7] = b.w;
     s = fe_from_mont(s);
+    uint32_t flip = 0;
+    if (centred) {
+        const Fr n = fe_neg(s);  // r - k (0 for k = 0)
+        bool lt = false;         // n < s, from the top limb down
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lt = (n.v[k] != s.v[k]) ? (n.v[k] < s.v[k]) : lt;
+        if (lt) {
+            s = n;
+            flip = 1;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) out[k] = s.v[k];
+    return flip;
 }
 
 __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
@@ -247,7 +270,7 @@ __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, u
         const uint64_t i = base + threadIdx.x + nt * e;
         if (i < m) {
             uint32_t v[8];
-            msm_load_canon(scalars, i, v);
+            (void)msm_load_canon(scalars, i, sh.centred, v);
             msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t) {
                 atomicAdd(&seg_h[msm_seg_of(sh, j, b)], 1u);
             });
@@ -257,12 +280,77 @@ __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, u
     for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) blk_hist[(uint64_t)s * sh.nblk + blockIdx.x] = seg_h[s];
 }
 
+// One launch instead of the three of the exclusive scan over the whole workgroup x segment matrix (short MSMs: three
+// 4.6-us launches between two 10-us kernels).  Workgroup s turns row s of the matrix into its exclusive prefix over the
+// workgroups (blk_base[s * nblk + b] = entries of segment s that workgroups < b hold) and publishes the row total
+// seg_tot[s]; the consumers add the segment's start, an exclusive scan of the <= 16K totals that each of their workgroups
+// redoes in LDS (msm_seg_starts).  Workgroup 0 also clears the bucket-schedule counters (`zero`).
+__global__ __launch_bounds__(256) void msm_seg_prefix_kernel(const uint32_t* __restrict__ blk_hist, uint32_t nblk,
+                                                             uint32_t* blk_base, uint32_t* seg_tot, uint32_t* zero,
+                                                             uint32_t nzero) {
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t running;
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const uint64_t row = (uint64_t)blockIdx.x * nblk;
+    for (uint32_t base = 0; base < nblk; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? blk_hist[row + i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            uint32_t t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = buf[threadIdx.x], r = running;
+        if (i < nblk) blk_base[row + i] = r + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) running = r + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) seg_tot[blockIdx.x] = running;
+}
+
+// start[s] = sum of seg_tot[0..s) for every segment, in LDS (nseg <= 16K), by all threads of the workgroup
+__device__ __forceinline__ void msm_seg_starts(const uint32_t* __restrict__ seg_tot, uint32_t nseg, uint32_t* start,
+                                               uint32_t* scratch /* blockDim.x words */) {
+    const uint32_t nt = blockDim.x, per = (nseg + nt - 1) / nt;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nseg);
+    uint32_t sum = 0;
+    for (uint32_t s = lo; s < hi; ++s) sum += seg_tot[s];
+    scratch[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < nt; off <<= 1) {
+        const uint32_t t = threadIdx.x >= off ? scratch[threadIdx.x - off] : 0;
+        __syncthreads();
+        scratch[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = scratch[threadIdx.x] - sum;
+    for (uint32_t s = lo; s < hi; ++s) {
+        start[s] = run;
+        run += seg_tot[s];
+    }
+    __syncthreads();
+}
+
+// seg_tot == nullptr: blk_base holds absolute positions (the three-launch scan); else row prefixes + segment totals
 __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
-                                                               const uint32_t* blk_base, uint32_t* entries) {
+                                                               const uint32_t* blk_base, const uint32_t* seg_tot,
+                                                               uint32_t* entries) {
     extern __shared__ uint32_t seg_sm[];
     uint32_t* cur = seg_sm;             // running position of this workgroup inside each segment
     const uint32_t nt = blockDim.x;
-    for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] = blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
+    if (seg_tot) {
+        msm_seg_starts(seg_tot, sh.nseg, cur, seg_sm + sh.nseg);
+        for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] += blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
+    } else {
+        for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] = blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
+    }
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
     const uint32_t lmask = (1u << sh.lb) - 1;
@@ -270,9 +358,10 @@ __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars
         const uint64_t i = base + threadIdx.x + nt * e;
         if (i < m) {
             uint32_t v[8];
-            msm_load_canon(scalars, i, v);
+            const uint32_t flip = msm_load_canon(scalars, i, sh.centred, v);
             msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
                 const uint32_t pos = atomicAdd(&cur[msm_seg_of(sh, j, b)], 1u);
+                neg ^= flip;
                 entries[pos] = (uint32_t)i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
                                ((b & lmask) << (sh.ibits + sh.jbits + 1));
             });
@@ -285,40 +374,59 @@ __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars
 // so any segment length works.
 // It also does what order_hist_kernel does for its own 2^lb buckets (their sizes are in registers here): the size
 // histogram of the bucket schedule and the task lists of heavy buckets -- one launch and one pass over counts[] fewer.
-__global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __restrict__ entries,
-                                                           const uint32_t* __restrict__ blk_base, MsmShape sh,
-                                                           uint32_t total_slot, uint32_t* counts, uint32_t* offsets,
-                                                           uint32_t* sorted, uint32_t cap, uint32_t* ohist, uint32_t* heavy,
-                                                           uint32_t* tasks) {
+__global__ __launch_bounds__(1024) void msm_seg_sort_kernel(const uint32_t* __restrict__ entries,
+                                                            const uint32_t* __restrict__ blk_base,
+                                                            const uint32_t* __restrict__ seg_tot, MsmShape sh,
+                                                            uint32_t total_slot, uint32_t* counts, uint32_t* offsets,
+                                                            uint32_t* sorted, uint32_t cap, uint32_t* ohist, uint32_t* heavy,
+                                                            uint32_t* tasks) {
+    // 256, 512 or 1024 threads: all of them walk the segment, the first 256 own the 2^lb <= 256 buckets
     __shared__ uint32_t hist[256];
     __shared__ uint32_t pref[256];
-    const uint32_t s = blockIdx.x;
-    const uint32_t start = blk_base[(uint64_t)s * sh.nblk];
-    const uint32_t end = (s + 1 < sh.nseg) ? blk_base[(uint64_t)(s + 1) * sh.nblk] : blk_base[total_slot];
-    hist[threadIdx.x] = 0;
+    __shared__ uint32_t red[1024];
+    const uint32_t s = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+    uint32_t start, end;
+    if (seg_tot) {  // segment start = sum of the totals before it
+        uint32_t sum = 0;
+        for (uint32_t i = tid; i < s; i += nt) sum += seg_tot[i];
+        red[tid] = sum;
+        __syncthreads();
+        for (uint32_t off = nt >> 1; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        start = red[0];
+        end = start + seg_tot[s];
+    } else {
+        start = blk_base[(uint64_t)s * sh.nblk];
+        end = (s + 1 < sh.nseg) ? blk_base[(uint64_t)(s + 1) * sh.nblk] : blk_base[total_slot];
+    }
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const uint32_t low_sh = sh.ibits + sh.jbits + 1;
-    for (uint32_t e = start + threadIdx.x; e < end; e += 256) atomicAdd(&hist[entries[e] >> low_sh], 1u);
+    for (uint32_t e = start + tid; e < end; e += nt) atomicAdd(&hist[entries[e] >> low_sh], 1u);
     __syncthreads();
-    const uint32_t mine = hist[threadIdx.x];
-    pref[threadIdx.x] = mine;
+    const uint32_t mine = tid < 256 ? hist[tid] : 0;
+    if (tid < 256) pref[tid] = mine;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t t = (int)threadIdx.x >= off ? pref[threadIdx.x - off] : 0;
+        const uint32_t t = (tid < 256 && (int)tid >= off) ? pref[tid - off] : 0;
         __syncthreads();
-        pref[threadIdx.x] += t;
+        if (tid < 256) pref[tid] += t;
         __syncthreads();
     }
-    const uint32_t excl = pref[threadIdx.x] - mine;
+    const uint32_t excl = tid < 256 ? pref[tid] - mine : 0;
     __syncthreads();
-    pref[threadIdx.x] = excl;
-    hist[threadIdx.x] = 0;
+    if (tid < 256) {
+        pref[tid] = excl;
+        hist[tid] = 0;
+    }
     const uint32_t nlow = 1u << sh.lb;
-    if (threadIdx.x < nlow) {
-        const uint32_t bucket = s * nlow + threadIdx.x;
+    if (tid < nlow) {
+        const uint32_t bucket = s * nlow + tid;
         counts[bucket] = mine;
         offsets[bucket] = start + excl;
-        if (s + 1 == sh.nseg && threadIdx.x + 1 == nlow) offsets[bucket + 1] = end;
+        if (s + 1 == sh.nseg && tid + 1 == nlow) offsets[bucket + 1] = end;
         if (mine > cap) {  // heavy bucket: the accumulate kernel takes the first cap entries, tasks the rest
             const uint32_t k = (mine - cap + cap - 1) / cap;
             const uint32_t hi = atomicAdd(&ohist[512], 1u);
@@ -336,18 +444,18 @@ __global__ __launch_bounds__(256) void msm_seg_sort_kernel(const uint32_t* __res
         }
     }
     __syncthreads();
-    // schedule histogram: hist[] is free until the scatter below re-zeroes... it IS the scatter's counter array, so the
-    // size bins are counted in pref-independent LDS first: reuse `hist` now, clear it again before the scatter
-    if (threadIdx.x < nlow) atomicAdd(&hist[min(mine, 255u)], 1u);
+    // schedule histogram (what order_hist_kernel would count for these buckets): size bins in `hist`, which is the
+    // scatter's counter array afterwards and is cleared again before the scatter
+    if (tid < nlow) atomicAdd(&hist[min(mine, 255u)], 1u);
     __syncthreads();
-    {
-        const uint32_t nbin = hist[threadIdx.x];
-        if (nbin) atomicAdd(&ohist[threadIdx.x], nbin);
+    if (tid < 256) {
+        const uint32_t nbin = hist[tid];
+        if (nbin) atomicAdd(&ohist[tid], nbin);
     }
     __syncthreads();
-    hist[threadIdx.x] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (uint32_t e = start + threadIdx.x; e < end; e += 256) {
+    for (uint32_t e = start + tid; e < end; e += nt) {
         const uint32_t v = entries[e];
         const uint32_t b = v >> low_sh;
         const uint32_t r = atomicAdd(&hist[b], 1u);
@@ -429,6 +537,37 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint32_t* coun
     if (g < n) order[blk[key] + rank] = g;
 }
 
+// order_scan_kernel + order_scatter_kernel in one launch: every workgroup scans the (complete) 256-bin size histogram
+// for itself and claims its run inside each bin from a zero-initialised global cursor (hist514[256..511])
+__global__ __launch_bounds__(256) void order_fused_kernel(const uint32_t* counts, uint32_t n, const uint32_t* hist,
+                                                          uint32_t* gcur, uint32_t* order) {
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t blk[256];
+    const uint32_t k = 255 - threadIdx.x;  // thread t scans size key 255 - t (descending order)
+    const uint32_t v = hist[k];
+    buf[threadIdx.x] = v;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const uint32_t base_k = buf[threadIdx.x] - v;  // buckets with a larger size key
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = 0, rank = 0;
+    if (g < n) {
+        key = min(counts[g], 255u);
+        rank = atomicAdd(&h[key], 1u);
+    }
+    __syncthreads();
+    blk[k] = base_k + (h[k] ? atomicAdd(&gcur[k], h[k]) : 0u);
+    __syncthreads();
+    if (g < n) order[blk[key] + rank] = g;
+}
+
 __global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const uint32_t* keys, uint64_t m, uint64_t total,
                                                                   uint32_t* cursor, uint32_t* sorted) {
     const uint64_t e = (uint64_t)blockIdx.x * MSM_THREADS + threadIdx.x;
@@ -469,15 +608,16 @@ uint32_t msm_segsort_blocks(uint64_t m) { return (uint32_t)((m + msm_chunk_for(m
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
-                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, hipStream_t s) {
+                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, bool centred, hipStream_t s) {
     MsmShape sh;
+    sh.centred = centred ? 1u : 0u;
     sh.c = c;
     sh.W = W;
     sh.top_v = top_v;
     sh.hb = hb;
     sh.lb = c - 1 - hb;
     sh.ibits = ibits;
-    sh.jbits = tlen ? 4 : 0;
+    sh.jbits = tlen ? (W > 16 ? 5 : 4) : 0;
     sh.tlen = tlen;
     sh.nsets = nsets;
     sh.nseg = (tlen ? nsets : W) << hb;
@@ -485,13 +625,24 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
     sh.nblk = (uint32_t)((m + sh.chunk - 1) / sh.chunk);
     const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
     const uint32_t nt1 = msm_seg1_threads();
+    static const bool scan3 = [] { const char* e = getenv("TYPLONK_MSM_SCAN"); return e && strcmp(e, "scan3") == 0; }();
+    // the fused row-prefix form scans the segment totals in LDS next to the scatter's cursors (nseg + nt1 words)
+    const bool fused = !scan3 && sh.nseg <= 8192;
+    uint32_t* seg_tot = fused ? scan_scratch : nullptr;
     hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
                        blk_hist);
-    launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, 514u, s);
-    hipLaunchKernelGGL(msm_seg_scatter_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
-                       blk_base, entries);
-    hipLaunchKernelGGL(msm_seg_sort_kernel, dim3(sh.nseg), dim3(256), 0, s, entries, blk_base, sh, (uint32_t)nmat, counts,
-                       offsets, sorted, cap, hist514, heavy, tasks);
+    if (fused)
+        hipLaunchKernelGGL(msm_seg_prefix_kernel, dim3(sh.nseg), dim3(256), 0, s, blk_hist, sh.nblk, blk_base, seg_tot, hist514,
+                           516u);
+    else
+        launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, 516u, s);
+    hipLaunchKernelGGL(msm_seg_scatter_kernel, dim3(sh.nblk), dim3(nt1), (fused ? sh.nseg + nt1 : sh.nseg) * sizeof(uint32_t),
+                       s, scalars, m, sh, blk_base, seg_tot, entries);
+    // long segments (short MSMs with few of them) get more threads per segment
+    const uint64_t seg_len = (uint64_t)sh.W * m / sh.nseg;
+    const uint32_t nt2 = seg_len >= 4096 ? 1024u : (seg_len >= 1536 ? 512u : 256u);
+    hipLaunchKernelGGL(msm_seg_sort_kernel, dim3(sh.nseg), dim3(nt2), 0, s, entries, blk_base, seg_tot, sh, (uint32_t)nmat,
+                       counts, offsets, sorted, cap, hist514, heavy, tasks);
 }
 
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
@@ -500,11 +651,16 @@ void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32
     // has filled the histogram and the heavy-bucket lists already (launch_msm_segsort)
     const uint32_t nblk = (n + 255) / 256;
     if (!hist_done) {
-        (void)hipMemsetAsync(hist514, 0, 514 * sizeof(uint32_t), s);
+        (void)hipMemsetAsync(hist514, 0, 516 * sizeof(uint32_t), s);
         hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, offsets, n, cap, hist514, heavy, tasks);
     }
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist514, hist514 + 256);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514 + 256, order);
+    static const bool split = [] { const char* e = getenv("TYPLONK_MSM_ORDER"); return e && strcmp(e, "split") == 0; }();
+    if (split) {  // the two-launch form (A/B measurements)
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist514, hist514 + 256);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514 + 256, order);
+        return;
+    }
+    hipLaunchKernelGGL(order_fused_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514, hist514 + 256, order);
 }
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
                         hipStream_t s) {
