@@ -44,6 +44,8 @@ extern "C" {
                                           panics (vanishes(), plonk/src/proof.rs:321, 361, 504-507) or produces a
                                           proof its own verifier rejects (:234-235)                          */
 
+#define TYPLONK_ERR_COMM (-9)          /* an RCCL call failed or librccl could not be loaded; see typlonk_last_error */
+
 typedef struct typlonk_ctx typlonk_ctx; /* one HIP device + stream + workspaces + cached NTT plans */
 typedef struct typlonk_buf typlonk_buf; /* device-resident vector of Fr elements                   */
 
@@ -74,8 +76,9 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
 /* Copy `count` points starting at `offset` back to the host (xy: count*12 limbs; inf: count or NULL). */
 int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_t count, uint64_t* xy, uint8_t* inf);
 /* Optional fixed-base precomputation (the SRS is immutable per circuit, plonk/src/lib.rs:22): builds the
- * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM, c = window_bits in
- * 16..20; 20 is the balanced choice: its top window still has 15 bits).  Later MSMs of at least len/4
+ * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM -- 15 for c = 17 and 17 for
+ * c = 15, which slice centred scalars |k| < 2^254 --, c = window_bits in 14..20, or 0 = chosen by length: 17 below
+ * 2^18 points -- an index shard --, else 20, whose top window still has 15 bits).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
  * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point.
  * An MSM length the table-mode sort cannot handle (more than 2^22 terms with 20-bit windows) silently takes the
@@ -85,10 +88,40 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
  * (one process per GPU, each with its own slice).  Every MSM / prover call on it then takes the FULL
  * coefficient vector (pointer to coefficient 0, global length m <= total_len, same length check as
  * kzg/src/lib.rs:43) and returns this rank's PARTIAL sum over its index range -- the identity if the range is
- * empty.  The caller all-gathers the partial points and folds them (typlonk_g1_sum_host). */
+ * empty.  The partial points are folded by typlonk_comm_fold_g1 / the *_sharded_* entry points below (RCCL), or by
+ * the caller's own exchange + typlonk_g1_sum_host. */
 int typlonk_srs_set_shard(typlonk_ctx* ctx, uint32_t srs_id, size_t first_index, size_t total_len);
 int typlonk_srs_free(typlonk_ctx* ctx, uint32_t srs_id);
 int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
+
+/* ---- multi-GPU exchange: one process per GPU, RCCL over xGMI ------------------------------------------------------
+ * The reference's evaluate_in_s returns the FULL sum (kzg/src/lib.rs:41-54); with the base vector index-sharded over
+ * the GPUs of a node (typlonk_srs_set_shard) the full sum is the fold of the ranks' partial sums.  RCCL has no
+ * elliptic-curve reduction, so the library's "all-reduce" is one ncclAllGather of 104-byte records (12 limbs + flag)
+ * on the context's stream followed by a fold in rank order 0..world-1 on every rank: the same bits everywhere.
+ * librccl is loaded on first use (dlopen "librccl.so.1"): single-GPU callers never need it.
+ *   typlonk_comm_unique_id   rank 0 creates the rendezvous id (ncclGetUniqueId) and hands the 128 bytes to the other
+ *                            ranks by whatever channel the host program has (a file, a socket, MPI, a Rust channel).
+ *   typlonk_comm_init        every rank: ncclCommInitRank on the context's device (collective: blocks until all
+ *                            `world` ranks have called it).  world = 1 is allowed (the exchange is then a local copy).
+ *   typlonk_comm_fold_g1     in place: count points in, on return each holds sum over ranks of that rank's point
+ *                            (collective).  What a caller that drives the prover rounds itself uses between rounds.
+ *   typlonk_msm_g1_sharded_devptr / _batch_devptr
+ *                            typlonk_msm_g1_devptr / _batch_devptr on an SRS shard + the fold: every rank passes the
+ *                            full coefficient vector(s) and gets the full sum(s) (collective).
+ * typlonk_prove on a context with a communicator and an SRS shard folds the commitments of every round itself, so
+ * all ranks hash identical points, squeeze identical challenges and return the identical proof. */
+#define TYPLONK_COMM_ID_BYTES 128
+int typlonk_comm_unique_id(uint8_t id[TYPLONK_COMM_ID_BYTES]);
+int typlonk_comm_init(typlonk_ctx* ctx, const uint8_t id[TYPLONK_COMM_ID_BYTES], int rank, int world);
+int typlonk_comm_destroy(typlonk_ctx* ctx);
+int typlonk_comm_info(const typlonk_ctx* ctx, int* rank, int* world); /* world = 0: no communicator */
+int typlonk_comm_fold_g1(typlonk_ctx* ctx, uint64_t* xy /* count*12, in/out */, uint8_t* inf /* count, in/out */,
+                         size_t count);
+int typlonk_msm_g1_sharded_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scalars, size_t m,
+                                  uint64_t out_xy[12], uint8_t* out_inf);
+int typlonk_msm_g1_sharded_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m,
+                                        size_t count, uint64_t* out_xy, uint8_t* out_inf);
 
 /* ---- MSM: sum_{i<m} scalars[i] * srs[i]  (== evaluate_in_s with coeffs = scalars) --------------- */
 /* scalars: m Fr elements (Montgomery).  0 <= m <= srs length, else TYPLONK_ERR_LENGTH.  m = 0 gives

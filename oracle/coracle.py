@@ -108,17 +108,31 @@ def poly_div_linear(coeffs, z_mont):
     return q, y
 
 
-def ntt(data, log_n, inverse=False, coset=None):
+def ntt(data, log_n, inverse=False, coset=None, threads=1):
+    """threads = 1: oracle_ntt (one thread, like the reference); 0 = all cores, k = k threads: oracle_ntt_mt (OpenMP)"""
     data = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).copy()
     assert data.shape[0] == (1 << log_n)
     cp = None
     if coset is not None:
         coset = np.ascontiguousarray(coset, dtype=np.uint64).reshape(4)
         cp = _p64(coset)
-    rc = lib().oracle_ntt(_p64(data), C.c_uint32(log_n), C.c_int(int(inverse)), cp)
+    if threads == 1:
+        rc = lib().oracle_ntt(_p64(data), C.c_uint32(log_n), C.c_int(int(inverse)), cp)
+    else:
+        rc = lib().oracle_ntt_mt(_p64(data), C.c_uint32(log_n), C.c_int(int(inverse)), cp, C.c_int(threads))
     if rc:
         raise AssertionError("GeneralEvaluationDomain::new(..).unwrap() failed (plonk/src/builder.rs:70)")
     return data
+
+
+def quotient_schoolbook_products(poly, n):
+    """the twelve naive_mul products of quotient_polynomial with their operand shapes, one thread (timing only)"""
+    poly = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
+    assert poly.shape[0] >= n
+    out = np.zeros(4, dtype=np.uint64)
+    rc = lib().oracle_quotient_schoolbook_products(_p64(poly), C.c_size_t(n), _p64(out))
+    assert rc == 0
+    return out
 
 
 def fr_vec_add(a, b):

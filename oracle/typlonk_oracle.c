@@ -461,3 +461,100 @@ int oracle_fr_vec_add(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* 
     for (size_t i = 0; i < n; ++i) fr_add((fr*)(out + 4 * i), (const fr*)(a + 4 * i), (const fr*)(b + 4 * i));
     return 0;
 }
+
+/* ======================================================================================================
+ * CPU BASELINES of bench.py -- still test infrastructure: the product never loads this.
+ *   oracle_quotient_schoolbook_products  R3: the twelve DensePolynomial::naive_mul products of quotient_polynomial
+ *                                        (/root/reference/plonk/src/proof.rs:317-359) with their operand shapes,
+ *                                        one thread like the reference; timing only (the operands are one vector)
+ *   oracle_ntt_mt                        F2: the same radix-2 transform as oracle_ntt with OpenMP over the
+ *                                        butterflies of a stage ("fair CPU": all cores)
+ * ====================================================================================================== */
+static void naive_mul(fr* out, const fr* a, size_t na, const fr* b, size_t nb) {   /* result[i + j] += a[i] * b[j] */
+    memset(out, 0, (na + nb - 1) * sizeof(fr));
+    for (size_t i = 0; i < na; ++i)
+        for (size_t j = 0; j < nb; ++j) { fr t; fr_mul(&t, &a[i], &b[j]); fr_add(&out[i + j], &out[i + j], &t); }
+}
+int oracle_quotient_schoolbook_products(const uint64_t* poly, size_t n, uint64_t checksum[4]) {
+    const fr* p = (const fr*)poly;
+    fr* t1 = (fr*)malloc(4 * n * sizeof(fr));
+    fr* t2 = (fr*)malloc(4 * n * sizeof(fr));
+    if (!t1 || !t2) { free(t1); free(t2); return -2; }
+    fr acc = {{0, 0, 0, 0}};
+    /* line 1 (:317-320): q_l a, q_r b, q_o c, (q_m a) b */
+    for (int k = 0; k < 3; ++k) { naive_mul(t1, p, n, p, n); fr_add(&acc, &acc, &t1[n]); }
+    naive_mul(t1, p, n, p, n); naive_mul(t2, t1, 2 * n - 1, p, n); fr_add(&acc, &acc, &t2[n]);
+    /* lines 2 and 3 (:322-348): ((f0 f1) f2) z twice */
+    for (int k = 0; k < 2; ++k) {
+        naive_mul(t1, p, n, p, n); naive_mul(t2, t1, 2 * n - 1, p, n); naive_mul(t1, t2, 3 * n - 2, p, n);
+        fr_add(&acc, &acc, &t1[n]);
+    }
+    /* line 4 (:355-359): (Z - 1) L0 */
+    naive_mul(t1, p, n, p, n); fr_add(&acc, &acc, &t1[n]);
+    memcpy(checksum, acc.v, 32);
+    free(t1); free(t2);
+    return 0;
+}
+
+static void fr_pow_big(fr* r, const fr* a, uint64_t e) { fr_pow_u64(r, a, e); }
+int oracle_ntt_mt(uint64_t* data, uint32_t log_n, int inverse, const uint64_t* coset_mont, int threads) {
+    if (log_n > 32) return -3;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+    const int64_t n = (int64_t)1 << log_n;
+    fr* a = (fr*)data;
+    fr root; fr_to_mont(&root, R_ROOT_CANON);
+    for (uint32_t i = log_n; i < 32; ++i) fr_mul(&root, &root, &root);
+    if (inverse) fr_inv(&root, &root);
+    const int64_t CH = 4096;   /* elements per task of the power-scaling loops */
+    if (!inverse && coset_mont) {
+        fr g; memcpy(g.v, coset_mont, 32);
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (int64_t c0 = 0; c0 < n; c0 += CH) {
+            fr x; fr_pow_big(&x, &g, (uint64_t)c0);
+            for (int64_t i = c0; i < c0 + CH && i < n; ++i) { fr_mul(&a[i], &a[i], &x); fr_mul(&x, &x, &g); }
+        }
+    }
+    const int64_t half = n / 2;
+    fr* tw = (fr*)malloc((size_t)(half ? half : 1) * sizeof(fr));
+    if (!tw) return -2;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t c0 = 0; c0 < half; c0 += CH) {
+        fr x; fr_pow_big(&x, &root, (uint64_t)c0);
+        for (int64_t j = c0; j < c0 + CH && j < half; ++j) { tw[j] = x; fr_mul(&x, &x, &root); }
+    }
+    int64_t gap = half, step = 1;
+    while (gap > 0) {
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (int64_t idx = 0; idx < half; ++idx) {
+            const int64_t start = (idx / gap) * 2 * gap, j = idx % gap;
+            fr u = a[start + j], v = a[start + j + gap], d;
+            fr_add(&a[start + j], &u, &v);
+            fr_sub(&d, &u, &v);
+            fr_mul(&a[start + j + gap], &d, &tw[j * step]);
+        }
+        gap >>= 1; step <<= 1;
+    }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t r = 0;
+        for (uint32_t b = 0; b < log_n; ++b) r |= ((i >> b) & 1) << (log_n - 1 - b);
+        if (i < r) { fr t = a[i]; a[i] = a[r]; a[r] = t; }
+    }
+    free(tw);
+    if (inverse) {
+        fr nn = {{(uint64_t)n, 0, 0, 0}}, nm, ninv; fr_to_mont(&nm, nn.v); fr_inv(&ninv, &nm);
+        fr gi; memcpy(gi.v, R_ONE, 32);
+        if (coset_mont) { fr g; memcpy(g.v, coset_mont, 32); fr_inv(&gi, &g); }
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (int64_t c0 = 0; c0 < n; c0 += CH) {
+            fr x = ninv;
+            if (coset_mont) { fr pw; fr_pow_big(&pw, &gi, (uint64_t)c0); fr_mul(&x, &x, &pw); }
+            for (int64_t i = c0; i < c0 + CH && i < n; ++i) { fr_mul(&a[i], &a[i], &x); if (coset_mont) fr_mul(&x, &x, &gi); }
+        }
+    }
+    return 0;
+}

@@ -59,3 +59,69 @@ def test_two_ranks_sharded_prove_equals_single_rank():
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"sharded_prove_ok"')]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     assert json.loads(lines[0])["sharded_prove_ok"] is True
+
+
+def test_native_rccl_exchange_behind_the_c_abi(built):
+    """typlonk_comm_* (RCCL loaded by the library itself, no torch.distributed anywhere): a one-rank communicator on the
+    test box's GPU.  typlonk_msm_g1_sharded_devptr / _batch_devptr and typlonk_comm_fold_g1 return what the local calls
+    return (the fold over one rank is the identity map on points, through ncclAllGather and the host fold), and
+    typlonk_prove on an SRS shard -- which folds every round's commitments -- equals typlonk_prove on the plain SRS."""
+    import numpy as np
+
+    import typlonk_amd
+    from helpers import O
+    from typlonk_amd.capi import TyplonkError, ERR_INVALID_ARG, comm_unique_id
+    from typlonk_amd.circuits import SquaringChain
+
+    ctx = typlonk_amd.Context(0)
+    try:
+        assert ctx.comm_info()[1] == 0
+        with pytest.raises(TyplonkError) as e:          # no communicator yet
+            ctx.comm_fold([(np.zeros(12, dtype=np.uint64), 1)])
+        assert e.value.code == ERR_INVALID_ARG
+        uid = comm_unique_id()
+        assert len(uid) == 128
+        ctx.comm_init(uid, 0, 1)
+        assert ctx.comm_info() == (0, 1)
+        log_n = 12
+        n = 1 << log_n
+        s_limbs = np.array(O.fr_to_mont_limbs(0xC0FFEE), dtype=np.uint64)
+        plain = ctx.srs_generate(s_limbs, n + 3)
+        shard = ctx.srs_generate(s_limbs, n + 3)
+        ctx.srs_set_shard(shard, 0, n + 3)
+        part = ctx.srs_generate(s_limbs, 1000, start=500)          # a proper sub-range
+        ctx.srs_set_shard(part, 500, n + 3)
+        rng = np.random.default_rng(5)
+        sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+        buf = ctx.alloc(n)
+        buf.upload(sc)
+        a = ctx.msm_devptr(plain, buf.devptr, n)
+        b = ctx.msm_sharded_devptr(shard, buf.devptr, n)
+        assert (a[0] == b[0]).all() and a[1] == b[1]
+        loc = ctx.msm_devptr(part, buf.devptr, n)
+        fol = ctx.msm_sharded_devptr(part, buf.devptr, n)
+        assert (loc[0] == fol[0]).all() and loc[1] == fol[1]
+        res = ctx.msm_sharded_batch_devptr(shard, [buf.devptr] * 3, [n, n - 1, 0])
+        ref = ctx.msm_batch_devptr(plain, [buf.devptr] * 3, [n, n - 1, 0])
+        for (x, i), (y, j) in zip(res, ref):
+            assert (x == y).all() and i == j
+        assert res[2][1] == 1                                         # the empty sum is the identity, also after the fold
+        pts = [a, loc, (np.zeros(12, dtype=np.uint64), 1)] * 7        # 21 points: more than the first reservation
+        back = ctx.comm_fold(pts)
+        for (x, i), (y, j) in zip(pts, back):
+            assert i == j and (j == 1 or (x == y).all())
+        chain = SquaringChain(ctx, log_n)
+        p0 = ctx.prove_native(plain, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+        p1 = ctx.prove_native(shard, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+        for key in ("commit", "t_commit", "witness"):
+            for (x, i), (y, j) in zip(p0[key], p1[key]):
+                assert (x == y).all() and i == j, key
+        assert (p0["z_commit"][0] == p1["z_commit"][0]).all()
+        for x, y in zip(p0["evals"], p1["evals"]):
+            assert (x == y).all()
+        chain.free()
+        buf.free()
+        ctx.comm_destroy()
+        assert ctx.comm_info()[1] == 0
+    finally:
+        ctx.close()

@@ -171,7 +171,7 @@ def test_library_loads_and_exports_every_declared_symbol(built):
     assert lib.typlonk_strerror(-2) == b"MSM length exceeds SRS length"
     # every error code of the header has its own text
     codes = {int(v) for v in re.findall(r"#define TYPLONK_ERR_[A-Z_]+ \((-\d+)\)", header)}
-    assert codes == set(range(-8, 0))
+    assert codes == set(range(-9, 0))
     texts = {lib.typlonk_strerror(c) for c in codes}
     assert len(texts) == len(codes) and b"unknown error" not in texts
     assert b"r(zeta)" in lib.typlonk_strerror(-8)

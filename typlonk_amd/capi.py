@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("TYPLONK_LIB_PATH") or os.path.join(_HERE, "libtyplonk
 
 OK = 0
 ERR_INVALID_ARG, ERR_LENGTH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RANGE, ERR_UNSATISFIED = -1, -2, -3, -4, -5, -6, -7, -8
+ERR_COMM = -9
+COMM_ID_BYTES = 128
 
 # every symbol include/typlonk.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -26,6 +28,8 @@ SYMBOLS = [
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
+    "typlonk_comm_unique_id", "typlonk_comm_init", "typlonk_comm_destroy", "typlonk_comm_info", "typlonk_comm_fold_g1",
+    "typlonk_msm_g1_sharded_devptr", "typlonk_msm_g1_sharded_batch_devptr",
 ]
 
 
@@ -108,6 +112,13 @@ def load_library() -> C.CDLL:
     lib.typlonk_msm_g1_dev.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_devptr.argtypes = [vp, C.c_uint32, vp, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_batch_devptr.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, u64p, u8p]
+    lib.typlonk_comm_unique_id.argtypes = [u8p]
+    lib.typlonk_comm_init.argtypes = [vp, u8p, C.c_int, C.c_int]
+    lib.typlonk_comm_destroy.argtypes = [vp]
+    lib.typlonk_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.typlonk_comm_fold_g1.argtypes = [vp, u64p, u8p, C.c_size_t]
+    lib.typlonk_msm_g1_sharded_devptr.argtypes = [vp, C.c_uint32, vp, C.c_size_t, u64p, u8p]
+    lib.typlonk_msm_g1_sharded_batch_devptr.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, u64p, u8p]
     lib.typlonk_ntt_fr.argtypes = [vp, u64p, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_devptr.argtypes = [vp, vp, C.c_uint32, C.c_int, u64p]
@@ -158,6 +169,16 @@ def _u8p(a: np.ndarray):
 def _as_u64(a, cols: int) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return a.reshape(-1, cols)
+
+
+def comm_unique_id() -> bytes:
+    """typlonk_comm_unique_id (rank 0): the 128-byte RCCL rendezvous id the other ranks need for Context.comm_init"""
+    lib = load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib.typlonk_comm_unique_id(buf)
+    if rc:
+        raise TyplonkError(rc, lib.typlonk_strerror(rc).decode())
+    return bytes(buf)
 
 
 def g1_sum_host(xy, inf=None):
@@ -335,6 +356,48 @@ class Context:
         out = np.zeros((n, 12), dtype=np.uint64)
         oinf = np.zeros(n, dtype=np.uint8)
         self._chk(self.lib.typlonk_msm_g1_batch_devptr(self.h, sid, ptrs, lens, n, _u64p(out), _u8p(oinf)))
+        return [(out[i], int(oinf[i])) for i in range(n)]
+
+    # ---- RCCL exchange behind the C ABI (typlonk_comm_*) -------------------------------------
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        """collective: ncclCommInitRank on this context's device"""
+        assert len(uid) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        self._chk(self.lib.typlonk_comm_init(self.h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._chk(self.lib.typlonk_comm_destroy(self.h))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        self._chk(self.lib.typlonk_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def comm_fold(self, points):
+        """typlonk_comm_fold_g1: [(xy[12], inf), ...] -> the same list with every point summed over the ranks"""
+        k = len(points)
+        xy = np.zeros((max(k, 1), 12), dtype=np.uint64)
+        inf = np.zeros(max(k, 1), dtype=np.uint8)
+        for i, (p, f) in enumerate(points):
+            xy[i] = np.asarray(p, dtype=np.uint64).reshape(12)
+            inf[i] = f
+        self._chk(self.lib.typlonk_comm_fold_g1(self.h, _u64p(xy), _u8p(inf), k))
+        return [(xy[i].copy(), int(inf[i])) for i in range(k)]
+
+    def msm_sharded_devptr(self, sid: int, devptr: int, m: int):
+        """typlonk_msm_g1_sharded_devptr: local partial MSM over the SRS shard + RCCL all-gather + fold (collective)"""
+        out = np.zeros(12, dtype=np.uint64)
+        oinf = np.zeros(1, dtype=np.uint8)
+        self._chk(self.lib.typlonk_msm_g1_sharded_devptr(self.h, sid, devptr, m, _u64p(out), _u8p(oinf)))
+        return out, int(oinf[0])
+
+    def msm_sharded_batch_devptr(self, sid: int, devptrs, ms):
+        n = len(devptrs)
+        ptrs = (C.c_void_p * n)(*devptrs)
+        lens = (C.c_size_t * n)(*ms)
+        out = np.zeros((n, 12), dtype=np.uint64)
+        oinf = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.typlonk_msm_g1_sharded_batch_devptr(self.h, sid, ptrs, lens, n, _u64p(out), _u8p(oinf)))
         return [(out[i], int(oinf[i])) for i in range(n)]
 
     def msm_plan(self, m: int):

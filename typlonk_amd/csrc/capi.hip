@@ -9,6 +9,9 @@
 #include "transcript.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen'ed on first use (typlonk_comm_*)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -102,6 +105,53 @@ struct typlonk_buf {
     size_t n = 0;
 };
 
+namespace {
+// RCCL entry points, resolved once per process.  The library is NOT linked: a single-GPU caller never loads it, and in
+// a process that already holds a copy (PyTorch's) dlopen by SONAME returns that copy, which is bound to the same HIP
+// runtime as this library there.
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    if (api.handle || !api.err.empty()) return &api;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) {
+        api.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+        return &api;
+    }
+    auto sym = [&](const char* n) -> void* {
+        void* f = dlsym(api.handle, n);
+        if (!f && api.err.empty()) api.err = std::string("librccl lacks ") + n;
+        return f;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    return &api;
+}
+constexpr size_t COMM_REC = 13;  // 12 limbs + the infinity flag, one u64 each: 104 bytes per point and rank
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 0;
+    uint64_t* d_send = nullptr;  // cap records
+    uint64_t* d_recv = nullptr;  // world * cap records
+    uint64_t* h_buf = nullptr;   // pinned: cap records out + world * cap records back
+    size_t cap = 0;
+};
+}  // namespace
+
 struct typlonk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -146,6 +196,7 @@ struct typlonk_ctx {
     int ntt_fr30 = 1;              // TYPLONK_NTT_FR30: 0 = off, 1 = 9 x 30-bit butterflies (fr30.hpp) up to 2^19,
                                    // 2 = for every transform (the 4096-element tiles of 2^20 are then not used)
     uint32_t ntt_full_max_log = 24;
+    Comm comm;                     // typlonk_comm_init: RCCL communicator of this rank (world = 0: none)
     bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
     bool msm_tree_reduce = false;  // TYPLONK_MSM_REDUCE=running: running-sum + small-multiple reduction (first version)
 };
@@ -858,13 +909,14 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         }
         {
             // lanes per bucket: a short MSM over a small bucket set has few, long buckets -- spread each over L lanes so
-            // that the launch fills the chip (>= 2^17 threads = two wavefronts per SIMD), as long as a lane keeps >= 4 terms
+            // that the launch fills the chip twice over (>= 2^18 threads: two rounds of two wavefronts per SIMD balance the
+            // size-sorted schedule; one round leaves the SIMDs with the largest buckets 30 % behind), while a lane keeps >= 4 terms
             uint32_t lanes = 1;
             if (ctx->msm_lanes) {
                 lanes = (uint32_t)ctx->msm_lanes;
             } else {
                 const uint64_t mean = total / nb_used;
-                while (lanes < 16 && nb_used * lanes < (1u << 17)) lanes *= 2;
+                while (lanes < 16 && nb_used * lanes < (1u << 18)) lanes *= 2;
                 while (lanes > 1 && mean / lanes < 4) lanes /= 2;
             }
             StageTimer st(ctx, "msm_accum", s);
@@ -1096,10 +1148,133 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
     return rc ? rc : r;
 }
 
+// ---- RCCL exchange ------------------------------------------------------------------------------------------------
+#define NCCLCHK(expr)                                                                                                 \
+    do {                                                                                                              \
+        ncclResult_t _r = (expr);                                                                                     \
+        if (_r != ncclSuccess)                                                                                        \
+            return fail(ctx, TYPLONK_ERR_COMM, std::string(#expr) + ": " + rccl_api()->GetErrorString(_r));           \
+    } while (0)
+
+void comm_release(typlonk_ctx* ctx) {
+    Comm& c = ctx->comm;
+    if (c.comm) (void)rccl_api()->CommDestroy(c.comm);
+    if (c.d_send) (void)hipFree(c.d_send);
+    if (c.d_recv) (void)hipFree(c.d_recv);
+    if (c.h_buf) (void)hipHostFree(c.h_buf);
+    c = Comm{};
+}
+
+int comm_reserve(typlonk_ctx* ctx, size_t count) {
+    Comm& c = ctx->comm;
+    if (c.cap >= count) return TYPLONK_OK;
+    const size_t cap = std::max<size_t>(16, count);
+    if (c.d_send) HIPCHK(hipFree(c.d_send));
+    if (c.d_recv) HIPCHK(hipFree(c.d_recv));
+    if (c.h_buf) HIPCHK(hipHostFree(c.h_buf));
+    c.d_send = c.d_recv = c.h_buf = nullptr;
+    c.cap = 0;
+    HIPCHK(hipMalloc((void**)&c.d_send, cap * COMM_REC * 8));
+    HIPCHK(hipMalloc((void**)&c.d_recv, (size_t)c.world * cap * COMM_REC * 8));
+    HIPCHK(hipHostMalloc((void**)&c.h_buf, (size_t)(c.world + 1) * cap * COMM_REC * 8));
+    c.cap = cap;
+    return TYPLONK_OK;
+}
+
+// every point <- sum over the ranks of that rank's point: all-gather of the records on the context's stream, fold in
+// rank order on the host (fixed order and a canonical result: bit-identical on every rank)
+int comm_fold(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count) {
+    Comm& c = ctx->comm;
+    if (!c.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
+    if (!count) return TYPLONK_OK;
+    int rc = comm_reserve(ctx, count);
+    if (rc) return rc;
+    uint64_t* out = c.h_buf;
+    uint64_t* back = c.h_buf + c.cap * COMM_REC;
+    for (size_t i = 0; i < count; ++i) {
+        memcpy(out + i * COMM_REC, xy + 12 * i, 96);
+        out[i * COMM_REC + 12] = inf[i];
+    }
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemcpyAsync(c.d_send, out, count * COMM_REC * 8, hipMemcpyHostToDevice, s));
+    NCCLCHK(rccl_api()->AllGather(c.d_send, c.d_recv, count * COMM_REC, ncclUint64, c.comm, s));
+    HIPCHK(hipMemcpyAsync(back, c.d_recv, (size_t)c.world * count * COMM_REC * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<uint64_t> pxy((size_t)c.world * 12);
+    std::vector<uint8_t> pinf((size_t)c.world);
+    for (size_t i = 0; i < count; ++i) {
+        for (int r = 0; r < c.world; ++r) {
+            const uint64_t* rec = back + ((size_t)r * count + i) * COMM_REC;
+            memcpy(&pxy[(size_t)r * 12], rec, 96);
+            pinf[(size_t)r] = (uint8_t)rec[12];
+        }
+        rc = typlonk_g1_sum_host(pxy.data(), pinf.data(), (size_t)c.world, xy + 12 * i, inf + i);
+        if (rc) return fail(ctx, rc, "fold of the gathered partial sums failed");
+    }
+    return TYPLONK_OK;
+}
+
+// does this MSM / prover call need the fold?  (an SRS shard on a context with a communicator)
+bool comm_folds(typlonk_ctx* ctx, uint32_t srs_id) {
+    if (!ctx->comm.comm) return false;
+    auto it = ctx->srs.find(srs_id);
+    return it != ctx->srs.end() && it->second.total_len != 0;
+}
+
 }  // namespace
 
 // ================================================================================================
 extern "C" {
+
+int typlonk_comm_unique_id(uint8_t id[TYPLONK_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == TYPLONK_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!id) return TYPLONK_ERR_INVALID_ARG;
+    RcclApi* api = rccl_api();
+    if (!api->err.empty()) return TYPLONK_ERR_COMM;
+    ncclUniqueId u;
+    if (api->GetUniqueId(&u) != ncclSuccess) return TYPLONK_ERR_COMM;
+    memcpy(id, &u, sizeof(u));
+    return TYPLONK_OK;
+}
+
+int typlonk_comm_init(typlonk_ctx* ctx, const uint8_t id[TYPLONK_COMM_ID_BYTES], int rank, int world) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "bad communicator arguments");
+    if (ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "this context already has a communicator");
+    RcclApi* api = rccl_api();
+    if (!api->err.empty()) return fail(ctx, TYPLONK_ERR_COMM, api->err);
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    NCCLCHK(api->CommInitRank(&comm, world, u, rank));
+    ctx->comm.comm = comm;
+    ctx->comm.rank = rank;
+    ctx->comm.world = world;
+    return TYPLONK_OK;
+}
+
+int typlonk_comm_destroy(typlonk_ctx* ctx) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    if (ctx->comm.comm) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    comm_release(ctx);
+    return TYPLONK_OK;
+}
+
+int typlonk_comm_info(const typlonk_ctx* ctx, int* rank, int* world) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    if (rank) *rank = ctx->comm.rank;
+    if (world) *world = ctx->comm.comm ? ctx->comm.world : 0;
+    return TYPLONK_OK;
+}
+
+int typlonk_comm_fold_g1(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count) {
+    if (!ctx || ((!xy || !inf) && count)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return comm_fold(ctx, xy, inf, count);
+}
 
 const char* typlonk_version(void) { return "typlonk-mi355x 0.1 (gfx950)"; }
 
@@ -1114,6 +1289,7 @@ const char* typlonk_strerror(int code) {
         case TYPLONK_ERR_OOM: return "device out of memory";
         case TYPLONK_ERR_RANGE: return "range outside device buffer";
         case TYPLONK_ERR_UNSATISFIED: return "witness does not satisfy the circuit (r(zeta) != 0)";
+        case TYPLONK_ERR_COMM: return "RCCL error";
         default: return "unknown error";
     }
 }
@@ -1188,6 +1364,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
         for (hipEvent_t e : ws.ev_acc)
             if (e) (void)hipEventDestroy(e);
     }
+    comm_release(ctx);
     for (hipStream_t l : ctx->lane)
         if (l) (void)hipStreamDestroy(l);
     for (hipEvent_t e : ctx->lane_evt)
@@ -1359,6 +1536,27 @@ int typlonk_msm_g1_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* c
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     return msm_batch(ctx, srs_id, d_scalars, m, count, out_xy, out_inf);
+}
+
+// evaluate_in_s over the whole node: this rank's partial sum over its SRS shard, then the fold of all ranks' sums
+int typlonk_msm_g1_sharded_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scalars, size_t m, uint64_t out_xy[12],
+                                  uint8_t* out_inf) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    if (!ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = msm_run(ctx, srs_id, (const Fr*)d_scalars, m, out_xy, out_inf);
+    if (rc) return rc;
+    return comm_fold(ctx, out_xy, out_inf, 1);
+}
+
+int typlonk_msm_g1_sharded_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m,
+                                        size_t count, uint64_t* out_xy, uint8_t* out_inf) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    if (!ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = msm_batch(ctx, srs_id, d_scalars, m, count, out_xy, out_inf);
+    if (rc) return rc;
+    return comm_fold(ctx, out_xy, out_inf, count);   // one collective for the whole group
 }
 
 int typlonk_msm_g1_dev(typlonk_ctx* ctx, uint32_t srs_id, const typlonk_buf* scalars, size_t offset, size_t m,
@@ -2126,6 +2324,15 @@ int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const 
     typlonk_prover* p = nullptr;
     int rc = typlonk_prover_round1(ctx, srs_id, circuit_id, wire_evals, pi_evals, &p, out->commit_xy, out->commit_inf);
     if (rc) return rc;
+    // An SRS shard on a context with a communicator: every round's partial commitments are folded over the ranks (one
+    // all-gather per round), so all ranks hash the same points and end with the same proof.  A failure on one rank
+    // only (an OOM, say) leaves its peers in the collective -- as any collective program -- so errors that every
+    // rank sees alike (unsatisfied witness, bad arguments) are the ones reported cleanly.
+    const bool folds = comm_folds(ctx, srs_id);
+    if (folds && (rc = comm_fold(ctx, &out->commit_xy[0][0], out->commit_inf, 3))) {
+        typlonk_prover_free(p);
+        return rc;
+    }
     // (beta, gamma) <- H([a], [b], [c])                                                   proof.rs:111
     ChallengeGenerator g;
     for (int i = 0; i < 3; ++i) g.digest(out->commit_xy[i], out->commit_inf[i]);
@@ -2134,6 +2341,7 @@ int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const 
     memcpy(out->beta, ch, 32);
     memcpy(out->gamma, ch + 4, 32);
     rc = typlonk_prover_round2(p, out->beta, out->gamma, cosets, out->z_xy, &out->z_inf);
+    if (!rc && folds) rc = comm_fold(ctx, out->z_xy, &out->z_inf, 1);
     if (!rc) {
         // (alpha, zeta) <- H([a], [b], [c], [Z])                                          proof.rs:133-136
         g.digest(out->z_xy, out->z_inf);
@@ -2141,6 +2349,20 @@ int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const 
         memcpy(out->alpha, ch, 32);
         memcpy(out->zeta, ch + 4, 32);
         rc = typlonk_prover_round3(p, out->alpha, out->zeta, &out->tail);
+        if (folds && (rc == TYPLONK_OK || rc == TYPLONK_ERR_UNSATISFIED)) {   // r(zeta) is the same on every rank
+            uint64_t xy[9][12];
+            uint8_t inf[9];
+            memcpy(xy, out->tail.t_xy, 3 * 96);
+            memcpy(xy + 3, out->tail.w_xy, 6 * 96);
+            memcpy(inf, out->tail.t_inf, 3);
+            memcpy(inf + 3, out->tail.w_inf, 6);
+            const int r2 = comm_fold(ctx, &xy[0][0], inf, 9);
+            memcpy(out->tail.t_xy, xy, 3 * 96);
+            memcpy(out->tail.w_xy, xy + 3, 6 * 96);
+            memcpy(out->tail.t_inf, inf, 3);
+            memcpy(out->tail.w_inf, inf + 3, 6);
+            if (r2) rc = r2;
+        }
     }
     typlonk_prover_free(p);
     return rc;

@@ -6,11 +6,15 @@ Each rank keeps its shard of the SRS resident in HBM (fixed chunking of the base
 shard boundaries do not depend on the MSM length m), runs the Pippenger MSM locally and produces
 one canonical affine partial point.  RCCL has no elliptic-curve reduction, so the "all-reduce" of
 the north-star is an all-gather of the G 13-word records (12 limbs + infinity flag) followed by a
-fold in fixed rank order 0..G-1 on every rank (typlonk_g1_sum_host) -- bit-identical everywhere.
+fold in fixed rank order 0..G-1 on every rank -- bit-identical everywhere.
 Message size is 104 B per rank: pure latency, xGMI bandwidth is irrelevant.
 
-The local MSM is injected as a callable so that the CPU (gloo, world_size 2) tests can exercise
-the sharding + exchange + fold without a GPU; the product wiring is `ShardedMsm`.
+The exchange itself lives BEHIND the C ABI (typlonk_comm_init, typlonk_msm_g1_sharded_devptr,
+typlonk_comm_fold_g1, and typlonk_prove on a shard: include/typlonk.h): this module is a thin caller
+that only carries the RCCL rendezvous id from rank 0 to the others over the torch.distributed group
+the launcher already set up.  The torch.distributed data path below (`allgather_fold*`) remains for
+the `gloo` backend: the world_size-2 CPU tests, and several ranks sharing ONE GPU on a 1-GPU box
+(RCCL refuses two ranks on the same device).
 """
 from __future__ import annotations
 
@@ -74,6 +78,15 @@ class ShardedMsm:
         # exercise the all-gather + fold even with one rank (used to validate the RCCL path on a 1-GPU box)
         import os
         self.force_collective = os.environ.get("TYPLONK_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
+        # the native exchange (RCCL inside the library) whenever the process group runs on RCCL
+        self.native = False
+        if dist.is_initialized() and dist.get_backend(group) == "nccl" and (world > 1 or self.force_collective) \
+                and os.environ.get("TYPLONK_NATIVE_COMM", "1") != "0":
+            from .capi import comm_unique_id
+            box = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group, device=device)
+            ctx.comm_init(box[0], rank, world)
+            self.native = True
 
     def generate_srs(self, secret_limbs):
         """build only this rank's slice [s^lo G, ..., s^(hi-1) G] in HBM"""
@@ -95,12 +108,16 @@ class ShardedMsm:
 
     def msm_devptr(self, d_scalars: int, m: int):
         """full m-term MSM result on every rank"""
+        if self.native:
+            return self.ctx.msm_sharded_devptr(self.sid, d_scalars, m)
         xy, inf = self.msm_local_devptr(d_scalars, m)
         if self.world == 1 and not self.force_collective:
             return xy, inf
         return allgather_fold(xy, inf, self.device, self.group)
 
     def fold(self, points):
+        if self.native:
+            return self.ctx.comm_fold(points)
         if self.world == 1 and not self.force_collective:
             return points
         return allgather_fold_many(points, self.device, self.group)
@@ -119,3 +136,8 @@ class ShardedProver:
     def prove(self, circuit: int, wire_evals, pi_evals, cosets, challenge12, challenge34, challenge_v=None):
         return self.sh.ctx.prove(self.sh.sid, circuit, wire_evals, pi_evals, cosets, challenge12, challenge34,
                                  challenge_v=challenge_v, fold=self.sh.fold)
+
+    def prove_native(self, circuit: int, wire_evals, pi_evals, cosets):
+        """typlonk_prove on the shard: the library folds every round's commitments itself (needs the native comm)"""
+        assert self.sh.native or self.sh.world == 1
+        return self.sh.ctx.prove_native(self.sh.sid, circuit, wire_evals, pi_evals, cosets)
