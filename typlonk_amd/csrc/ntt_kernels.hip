@@ -36,6 +36,95 @@ __device__ __forceinline__ Fr ntt_pow2l(const Fr* lo, const Fr* hi, uint32_t h, 
     return fe_mul(ntt_ld(lo + (e & ((1ull << h) - 1))), ntt_ld(hi + (e >> h)));
 }
 
+// ---- register-resident radix-4 stage groups -------------------------------------------------------------------------
+// The radix-2 form below makes one LDS round trip (two loads, two stores, a __syncthreads) per stage: ten per 2^10-point
+// sub-transform.  Here a thread takes the four elements of two consecutive DIF stages -- i0 + j * quarter, j = 0..3,
+// quarter = half / 2 -- does both stages in registers and stores them back in place: five round trips for k = 10, the
+// same multiplications in the same order on every element (so the results, and the lazy bounds of the 30-bit form,
+// are those of the radix-2 stages).  An odd k starts with one radix-2 stage, so that the LAST group is always the
+// one with half = 2, 1, whose twiddles are 1 except w^(M/4): one multiplication per four elements.
+//   stage s     (x0, x2) pos = low, (x1, x3) pos = low + quarter;   twiddle w^(pos << s)
+//   stage s + 1 (x0', x1') and (x2', x3'), both pos = low;          twiddle w^(low << (s + 1))
+struct NttArith32 {
+    using E = Fr;
+    using P = Fr*;
+    static __device__ __forceinline__ E ld(P tile, uint32_t idx) { return ntt_ld(tile + idx); }
+    static __device__ __forceinline__ void st(P tile, uint32_t idx, const E& x) { ntt_st(tile + idx, x); }
+    static __device__ __forceinline__ E add(const E& a, const E& b) { return fe_add(a, b); }
+    static __device__ __forceinline__ E sub(const E& a, const E& b) { return fe_sub(a, b); }
+    static __device__ __forceinline__ E mul(const E& a, const E& b) { return fe_mul(a, b); }
+};
+struct NttArith30 {
+    using E = Fr30;
+    using P = uint32_t*;
+    static __device__ __forceinline__ E ld(P tile, uint32_t idx) {
+        E r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.v[i] = tile[9 * idx + i];
+        return r;
+    }
+    static __device__ __forceinline__ void st(P tile, uint32_t idx, const E& x) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tile[9 * idx + i] = x.v[i];
+    }
+    static __device__ __forceinline__ E add(const E& a, const E& b) { return fr30_add(a, b); }
+    static __device__ __forceinline__ E sub(const E& a, const E& b) { return fr30_sub(a, b); }
+    static __device__ __forceinline__ E mul(const E& a, const E& b) { return fr30_mul(a, b); }
+};
+
+template <class A>
+__device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A::P stw, uint32_t k, uint32_t logT, uint32_t E,
+                                                  uint32_t tid, uint32_t nt) {
+    using El = typename A::E;
+    const uint32_t T = 1u << logT;
+    uint32_t s = 0;
+    if (k & 1u) {  // the odd stage first: half = 2^(k-1)
+        const uint32_t lh = k - 1, half = 1u << lh;
+        for (uint32_t qq = tid; qq < (E >> 1); qq += nt) {
+            const uint32_t t = qq & (T - 1), pos = qq >> logT;   // one butterfly per (pos, t): j < half, so pos = j
+            const uint32_t ia = (pos << logT) + t, ib = ((pos + half) << logT) + t;
+            const El x = A::ld(tile, ia), y = A::ld(tile, ib);
+            A::st(tile, ia, A::add(x, y));
+            const El d = A::sub(x, y);
+            A::st(tile, ib, lh == 0 ? d : A::mul(d, A::ld(stw, pos)));
+        }
+        __syncthreads();
+        s = 1;
+    }
+    for (; s + 1 < k; s += 2) {
+        const uint32_t lh = k - 1 - s;          // log2(half) of stage s, >= 1
+        const uint32_t quarter = 1u << (lh - 1);
+        const bool lastg = lh == 1;             // stages with half = 2, 1: low = 0
+        for (uint32_t g = tid; g < (E >> 2); g += nt) {
+            const uint32_t t = g & (T - 1), rest = g >> logT;
+            const uint32_t low = rest & (quarter - 1), hi = rest >> (lh - 1);
+            const uint32_t i0 = (hi << (lh + 1)) + low;
+            const uint32_t a0 = (i0 << logT) + t, a1 = a0 + (quarter << logT), a2 = a1 + (quarter << logT),
+                           a3 = a2 + (quarter << logT);
+            const El x0 = A::ld(tile, a0), x1 = A::ld(tile, a1), x2 = A::ld(tile, a2), x3 = A::ld(tile, a3);
+            const El s0 = A::add(x0, x2), s1 = A::add(x1, x3);
+            El d0 = A::sub(x0, x2), d1 = A::sub(x1, x3);
+            if (!lastg) {
+                d0 = A::mul(d0, A::ld(stw, low << s));
+                d1 = A::mul(d1, A::ld(stw, (low + quarter) << s));
+            } else {
+                d1 = A::mul(d1, A::ld(stw, 1u << s));   // w^(M/4); d0's twiddle is 1
+            }
+            El y1 = A::sub(s0, s1), y3 = A::sub(d0, d1);
+            if (!lastg) {
+                const El tw = A::ld(stw, low << (s + 1));
+                y1 = A::mul(y1, tw);
+                y3 = A::mul(y3, tw);
+            }
+            A::st(tile, a0, A::add(s0, s1));
+            A::st(tile, a1, y1);
+            A::st(tile, a2, A::add(d0, d1));
+            A::st(tile, a3, y3);
+        }
+        __syncthreads();
+    }
+}
+
 // 256 threads on tiles of <= 1024 elements (32 KiB of LDS), or 1024 threads on tiles of <= 4096 elements (128 KiB:
 // one workgroup per CU) when a 2^17..2^20 transform is done in two passes instead of three (capi.hip, ntt_run)
 __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
@@ -84,7 +173,8 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     // skipped -- 0.75 of the k/2 multiplications per element of a pass (19 % of a 2^20 transform's).  For half = 2 the
     // butterflies are dealt out so that a whole sweep of the workgroup has the same pos (no divergence inside a wave).
     const uint32_t nb = E >> 1;
-    for (uint32_t s = 0; s < k; ++s) {
+    if (a.radix4) ntt_stages_radix4<NttArith32>(tile, stw, k, logT, E, tid, NTT_THREADS);
+    for (uint32_t s = a.radix4 ? k : 0u; s < k; ++s) {
         const uint32_t lh = k - 1 - s;  // log2(half)
         const uint32_t half = 1u << lh;
         const bool split = (lh == 1) && (nb >= 2 * NTT_THREADS);  // sweep 2r: pos 0, sweep 2r + 1: pos 1
@@ -200,7 +290,8 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     __syncthreads();
 
     const uint32_t nb = E >> 1;
-    for (uint32_t s = 0; s < k; ++s) {
+    if (a.radix4) ntt_stages_radix4<NttArith30>(tile, stw, k, logT, E, tid, NTT_THREADS);
+    for (uint32_t s = a.radix4 ? k : 0u; s < k; ++s) {
         const uint32_t lh = k - 1 - s;
         const uint32_t half = 1u << lh;
         const bool split = (lh == 1) && (nb >= 2 * NTT_THREADS);
