@@ -543,7 +543,7 @@ def bench_cpu(args, ctx, sh, full, n, log_n, secret, out_xy, out_inf, result) ->
         from typlonk_amd.circuits import SquaringChain
 
         lg = min(16, log_n)
-        chain = SquaringChain(ctx, lg)
+        chain = SquaringChain(ctx, lg, keep_host=True)
         try:
             sid16 = ctx.srs_generate(secret, (1 << lg) + 3)
             ctx.srs_precompute(sid16, 20)

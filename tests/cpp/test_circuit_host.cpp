@@ -45,11 +45,12 @@ struct Chain1000 : plonk::CircuitDescription<2, Chain1000> {  // y == x^(2^500) 
     }
 };
 
-struct SquaringChain20 : plonk::CircuitDescription<1, SquaringChain20> {  // 2^20 - 3 gates: BASELINE config 3's size
+template <int LOG>
+struct SquaringChainN : plonk::CircuitDescription<1, SquaringChainN<LOG>> {  // 2^LOG - 3 gates: BASELINE configs 3 and 5
     template <class V>
     static void run(std::array<V, 1> in) {
         V x = in[0];
-        for (int i = 0; i < (1 << 20) - 3; ++i) x = x.clone() * x;
+        for (int i = 0; i < (1 << LOG) - 3; ++i) x = x.clone() * x;
     }
 };
 
@@ -58,12 +59,13 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// `test_circuit_host big`: the 2^20-row circuit through the same front end -- build, prove twice, verify
+// `test_circuit_host big [22]`: the 2^20-row (2^22-row) circuit through the same front end -- build, prove twice, verify
+template <int LOG>
 static int big(const Context& ctx) {
     double t0 = now_ms();
-    auto circuit = SquaringChain20::build(ctx);
+    auto circuit = SquaringChainN<LOG>::build(ctx);
     const double t_build = now_ms() - t0;
-    REQUIRE(circuit.rows == (size_t)1 << 20);
+    REQUIRE(circuit.rows == (size_t)1 << LOG);
     t0 = now_ms();
     auto proof = circuit.prove({3}, {0});
     const double t_first = now_ms() - t0;
@@ -84,7 +86,7 @@ static int big(const Context& ctx) {
 
 int main(int argc, char** argv) {
     Context ctx(0);
-    if (argc > 1 && std::string(argv[1]) == "big") return big(ctx);
+    if (argc > 1 && std::string(argv[1]) == "big") return (argc > 2 && std::string(argv[2]) == "22") ? big<22>(ctx) : big<20>(ctx);
     {   // circuit2_test
         auto circuit = Circuit2::build(ctx);
         REQUIRE(circuit.rows == 8);

@@ -61,6 +61,26 @@ def test_two_ranks_sharded_prove_equals_single_rank():
     assert json.loads(lines[0])["sharded_prove_ok"] is True
 
 
+def test_config4_eight_ranks_share_the_gpu_at_2_20():
+    """BASELINE config 4 at its own size on the one GPU of the test box: the 2^20-row circuit with every MSM index-sharded
+    over EIGHT ranks (gloo: RCCL refuses several ranks per device; each rank has its own context, SRS shard of 2^17
+    points and c = 17 tables).  bench.py's headline loop: the folded commitment equals [p(s)]G; the worker: the sharded
+    proof -- both shapes -- equals the proof of one rank holding the whole SRS, element for element, r(zeta) = 0."""
+    d = _run({"TYPLONK_BENCH_BACKEND": "gloo", "TYPLONK_BENCH_PG_TIMEOUT": "600"}, 8,
+             ["--gpus", "8", "--steps", "3", "--warmup", "1", "--log-n", "20"])
+    assert d["n_gpus"] == 8 and d["parity"]["full_commit_identity"] is True and d["value"] is not None
+    assert d["prove_valid"] is True and "prove_sharded_error" not in d and "error" not in d
+    assert "c=17" in d["config"]["fixed_base_tables"]
+    env = dict(os.environ, LOG_N="20", TABLES="auto")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_prove_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"sharded_prove_ok"')]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["sharded_prove_ok"] is True and out["world"] == 8 and out["log_n"] == 20
+
+
 def test_native_rccl_exchange_behind_the_c_abi(built):
     """typlonk_comm_* (RCCL loaded by the library itself, no torch.distributed anywhere): a one-rank communicator on the
     test box's GPU.  typlonk_msm_g1_sharded_devptr / _batch_devptr and typlonk_comm_fold_g1 return what the local calls

@@ -388,3 +388,71 @@ def test_native_prove_equals_the_round_by_round_flow(ctx, log_n):
         b.free()
     ctx.circuit_free(cid)
     ctx.srs_free(sid)
+
+
+def test_config5_prove_at_2_22_both_shapes(ctx):
+    """BASELINE config 5's size, n = 2^22 (quotient domain 2^24): a full prove() in both proof shapes on one GPU.
+    r(zeta) = 0; the wire commitments equal [p(s)]G with p = iNTT(wire column) evaluated by the C oracle (the reference's
+    test identity, kzg/src/lib.rs:102-105); every opening witness satisfies the verifier's equation in trapdoor form,
+    (s - z) W = C - y G (kzg/src/lib.rs:66-81 with the pairing replaced by the known secret) -- for [r] with the
+    verifier's own linearisation commitment (proof.rs:441-503) built from the proof's and the circuit's commitments;
+    the batched witness is the v-combination of the six-opening proof's witnesses.  (The pairing verifier itself runs
+    on a 2^22 proof in tests/test_host_mirror.py.)"""
+    from oracle import coracle as CO
+    from oracle import pairing as PR
+    from typlonk_amd.circuits import SquaringChain
+
+    log_n = 22
+    n = 1 << log_n
+    secret = 0x0123456789ABCDEF0123456789ABCDEF
+    s_l = _limbs(secret)
+    chain = SquaringChain(ctx, log_n, keep_host=True)
+    sid = ctx.srs_generate(s_l, n + 3)
+    ctx.srs_precompute(sid, 20)
+    alpha, beta, gamma = CH
+    v = 0x1F2E3D4C5B6A7988
+    chal = (lambda c: (_limbs(beta), _limbs(gamma)), lambda c: (_limbs(alpha), _limbs(ZETA)))
+    six = ctx.prove(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets, *chal)
+    bat = ctx.prove(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets, *chal, challenge_v=lambda e: _limbs(v))
+    pt = lambda t: g1_unpack_one(t[0], t[1])                   # noqa: E731
+    fr = lambda a: O.fr_from_mont_limbs([int(x) for x in a])   # noqa: E731
+    ev = [fr(e) for e in six["evals"]]
+    assert ev[5] == 0 and [fr(e) for e in bat["evals"]] == ev
+    host = chain.host_inputs()
+
+    def at_s(evals):      # p(s) for p = interpolate(evals)
+        coeffs = CO.ntt(evals, log_n, inverse=True, threads=0)
+        return coeffs, fr(CO.poly_eval(coeffs, s_l))
+
+    commits = [pt(c) for c in six["commit"]]
+    for i in range(3):
+        _, ps = at_s(host["wires"][i])
+        assert commits[i] == O.g1_mul(O.G1, ps), f"wire commitment {i}"
+    assert [pt(c) for c in bat["commit"]] == commits and pt(bat["z_commit"]) == pt(six["z_commit"])
+    assert [pt(c) for c in bat["t_commit"]] == [pt(c) for c in six["t_commit"]]
+    # openings in trapdoor form
+    w = O.domain_root(log_n)
+    wit = [pt(x) for x in six["witness"]]
+    zc = pt(six["z_commit"])
+    trapdoor = lambda W, C, z, y: O.g1_mul(W, (secret - z) % O.R) == O.g1_add(C, O.g1_neg(O.g1_mul(O.G1, y)))   # noqa: E731
+    for i in range(3):
+        assert trapdoor(wit[i], commits[i], ZETA, ev[i]), f"opening {i}"
+    assert trapdoor(wit[3], zc, ZETA, ev[3]) and trapdoor(wit[4], zc, ZETA * w % O.R, ev[4])
+    # [r]: the verifier's linearisation commitment from commitments only
+    sel_c, sel_s = at_s(host["selectors"][2])                  # q_o = q_m; q_l = q_r = q_c = 0
+    q_pt = O.g1_mul(O.G1, sel_s)
+    fixed = [None, None, q_pt, q_pt, None]
+    sig = [at_s(x) for x in host["sigma"]]
+    sigma_c = [O.g1_mul(O.G1, ps) for _, ps in sig]
+    sigma_ev = [fr(CO.poly_eval(cf, _limbs(ZETA))) for cf, _ in sig]
+    r_commit = PR.linearisation_commitment(log_n, fixed, sigma_c, sigma_ev, PO.COSETS, ev[:3], zc, (ev[3], ev[4]), ZETA,
+                                           [pt(c) for c in six["t_commit"]], (alpha, beta, gamma), 0)
+    assert trapdoor(wit[5], r_commit, ZETA, 0), "opening of r"
+    # batched shape: W = W_a + v W_b + v^2 W_c + v^3 W_Z + v^4 W_r (division by X - zeta is linear), W_zw unchanged
+    bw = [pt(x) for x in bat["witness"]]
+    comb = None
+    for k, i in enumerate((0, 1, 2, 3, 5)):
+        comb = O.g1_add(comb, O.g1_mul(wit[i], pow(v, k, O.R)))
+    assert bw[0] == comb and bw[1] == wit[4]
+    chain.free()
+    ctx.srs_free(sid)

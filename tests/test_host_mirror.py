@@ -127,6 +127,14 @@ def test_a_2_20_row_circuit_through_the_cpp_front_end(built):
     assert "rows=1048576" in out
 
 
+@pytest.mark.gpu
+def test_a_2_22_row_circuit_is_proved_and_accepted_by_the_pairing_verifier(built):
+    """BASELINE config 5's size (n = 2^22): the same C++ program -- typlonk_prove on the GPU, then the restated
+    plonk::proof::verify with real pairings accepts the proof and rejects a changed evaluation"""
+    out = _run("test_circuit_host", "big", "22")
+    assert "rows=4194304" in out and "all ok" in out
+
+
 @pytest.mark.parametrize("name", ["test_poly_host", "test_circuit_tables_host"])
 def test_host_mirror_under_address_and_ub_sanitizers(built, tmp_path, name):
     """the host-side C++ (typlonk_host.hpp, circuit_host.hpp + the shared field headers) compiled with ASan + UBSan on the

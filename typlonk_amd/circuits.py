@@ -44,7 +44,9 @@ def _to_montgomery(ctx: Context, canon: np.ndarray) -> DeviceBuffer:
 class SquaringChain:
     """Device-resident circuit tables + witness for n = 2^log_n rows."""
 
-    def __init__(self, ctx: Context, log_n: int, x0: int = 3, blinder_seed: int = 0x5EED0000):
+    def __init__(self, ctx: Context, log_n: int, x0: int = 3, blinder_seed: int = 0x5EED0000, keep_host: bool = False):
+        """keep_host: keep the host copies of the selector / sigma evaluation tables (host_inputs(): what a CPU prover or
+        a verifier-side check needs; 8 x 32 n bytes)"""
         self.ctx, self.log_n = ctx, log_n
         n = self.n = 1 << log_n
         g = self.gates = n - 3
@@ -95,6 +97,14 @@ class SquaringChain:
         for b in bufs:
             b.free()
         self.cosets = [fr_mont_limbs(k) for k in COSETS]
+        self._host = {"selectors": sel_evals, "sigma": [sa, sb, sc]} if keep_host else None
+
+    def host_inputs(self):
+        """the prover's inputs as host arrays of Montgomery limbs: wire / selector / sigma evaluations over the domain"""
+        if self._host is None:
+            raise RuntimeError("SquaringChain(keep_host=True) keeps the host tables")
+        return {"log_n": self.log_n, "wires": [b.download() for b in self.wire_evals], "selectors": self._host["selectors"],
+                "sigma": self._host["sigma"], "cosets": list(COSETS)}
 
     def free(self):
         self.ctx.circuit_free(self.circuit)
