@@ -26,5 +26,5 @@ for k, name in enumerate(shape):
     tot_busy += dur
     print(f"{off:8.1f} us  +{dur:7.1f} us  -> {end_off:8.1f}  gap {gap:6.1f}  {name}")
 span = sum(max(x[1] for x in s) - s[0][0] for s in seqs) / n / 1e3
-period = (starts and (rows[starts[-1]][0] - rows[starts[0]][0]) / (len(starts) - 1) / 1e3) or 0
+period = (rows[min(starts[-1], len(rows) - 1)][0] - rows[starts[0]][0]) / (len(starts) - 1) / 1e3 if len(starts) > 1 else 0
 print(f"kernel span {span:.1f} us, kernel time {tot_busy:.1f} us, MSM period {period:.1f} us")

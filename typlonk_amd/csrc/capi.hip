@@ -187,6 +187,7 @@ struct typlonk_ctx {
     // bit 2 = first opening MSMs of round 3 submitted before the quotient
     int prover_overlap = 3;   // measured (profiles/r02_ab_prover_overlap.txt): bits 0-1 gain ~1 %, bit 2 loses ~1 %
     int msm_chunks = 0;            // TYPLONK_MSM_CHUNKS: chunks of a stand-alone MSM (0 = choose by length)
+    bool msm_stagger = true;       // TYPLONK_MSM_STAGGER=0: the second chunk's sort runs beside the first one's (round-2 order)
     int msm_lanes = 0;             // TYPLONK_MSM_LANES: lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_rc4 = false;          // TYPLONK_MSM_REDUCE=rc4: always the four-launch row/column reduction (round-2 form)
     bool msm_rc2_force = false;    // TYPLONK_MSM_REDUCE=rc2: the two-launch form for every bucket-set size
@@ -848,6 +849,9 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         SortBufs& sb = ws.sb[k & 1];
         hipStream_t ss = (nch > 1 && k > 0) ? ws.side : s;   // the first sort has nothing to overlap with
         if (nch > 1 && k >= 2 && ss != s) HIPCHK(hipStreamWaitEvent(ss, ws.ev_acc[k - 2], 0));  // sb[k & 1] is free again
+        // the first chunk's sort is the exposed one: the second chunk's sort starts behind it (it then has the whole first
+        // accumulation to hide under) instead of beside it, where it doubled its time (profiles/r03_msm_2_20_timeline.txt)
+        if (nch > 1 && k == 1 && ctx->msm_stagger) HIPCHK(hipStreamWaitEvent(ss, ws.ev_sorted[0], 0));
         const uint64_t total = (uint64_t)W * mk;
         if ((rc = ensure(ctx, sb.keys, total * 4))) return rc;
         if ((rc = ensure(ctx, sb.sorted, total * 4))) return rc;
@@ -908,6 +912,8 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if (ss != s) {
             HIPCHK(hipEventRecord(ws.ev_sorted[k], ss));
             HIPCHK(hipStreamWaitEvent(s, ws.ev_sorted[k], 0));
+        } else if (nch > 1 && k == 0) {
+            HIPCHK(hipEventRecord(ws.ev_sorted[0], s));
         }
         {
             // lanes per bucket: a short MSM over a small bucket set has few, long buckets -- spread each over L lanes so
@@ -1324,6 +1330,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         ctx->msm_rc4 = (strcmp(e, "rc4") == 0);
         ctx->msm_rc2_force = (strcmp(e, "rc2") == 0);
     }
+    if (const char* e = getenv("TYPLONK_MSM_STAGGER")) ctx->msm_stagger = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
         const int l = atoi(e);
         if (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) ctx->msm_lanes = l;

@@ -186,9 +186,8 @@ inline uint32_t msm_seg1_per_thread(uint64_t m) {
         return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0);
     }();
     if (forced) return forced;
-    uint32_t per = 8;
-    while (per > 1 && (uint64_t)per * msm_seg1_threads() * 512 > m) per >>= 1;
-    return per;
+    // (2^19-term chunks keep 8: their scatter, 4096 segments wide, wants long runs per workgroup and segment)
+    return m <= (1u << 17) ? 1u : (m <= (1u << 18) ? 2u : 8u);
 }
 inline uint32_t msm_chunk_for(uint64_t m) {
     uint32_t chunk = msm_seg1_per_thread(m) * msm_seg1_threads();
