@@ -4,6 +4,7 @@
 // All Fq / G1 arguments are in the C-ABI (arkworks) form: 12 u32 words per coordinate, R = 2^384.
 #include "../../typlonk_amd/csrc/g1.hpp"
 #include "../../typlonk_amd/csrc/g1_host64.hpp"
+#include "../../typlonk_amd/csrc/transcript.hpp"
 #include <string.h>
 using namespace ty;
 
@@ -126,5 +127,15 @@ int shim_h64_chain(const uint32_t* pts, int n, int ndbl, const uint32_t* z, uint
     if (!H::xyzz_to_affine(acc, xy)) return 0;
     memcpy(o, xy, 96);
     return 1;
+}
+
+// the native transcript's generator (csrc/transcript.hpp), for the published known-answer vectors of the crates
+void shim_stdrng_words(const uint32_t key[8], uint64_t* out, int n) {   // StdRng::from_seed(key) -> n x next_u64
+    ty::StdRng r = ty::StdRng::from_key(key);
+    for (int i = 0; i < n; ++i) out[i] = r.next_u64();
+}
+void shim_seed_from_u64(uint64_t state, uint32_t key_out[8]) {          // rand_core SeedableRng::seed_from_u64 expansion
+    ty::StdRng r(state);
+    for (int i = 0; i < 8; ++i) key_out[i] = r.key[i];
 }
 }

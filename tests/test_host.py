@@ -273,3 +273,40 @@ def test_native_transcript_equals_the_python_statement(built):
             assert len(a) == len(b) == n and all((x == y).all() for x, y in zip(a, b)), (k, n)
             for x in a:   # a valid Montgomery residue: the limbs read as an integer are below r
                 assert sum(int(v) << (64 * i) for i, v in enumerate(x)) < O.R
+
+
+def test_transcript_generator_against_the_crates_published_vectors(built):
+    """Known answers that come from OUTSIDE this repository, reproduced by both statements of the generator
+    (tests/transcript_ref.py and csrc/transcript.hpp through the host shim):
+      * ChaCha12, 256-bit zero key, zero counter/nonce: keystream block of draft-strombergson-chacha-test-vectors-01
+        (TC1, 12 rounds) -- the block function at the round count rand 0.8's StdRng uses;
+      * rand 0.8 `rngs::std::test_stdrng_construction`: StdRng::from_seed([1,0,0,0, 23,0,0,0, 200,1,0,0, 210,30,0,0,
+        0...]).next_u64() == 10719222850664546238 -- pins the 64-bit block counter layout, the 12 rounds and the order
+        in which two 32-bit words make a u64;
+      * rand_chacha `test_chacha_construction` (ChaCha20Rng): seed words 0,0,1,0,2,0,3,0 -> next_u32() == 137206642.
+    Not covered by any published vector known here: the PCG32 expansion of seed_from_u64 (only its constants are
+    standard) and ark-ff's Fr::rand shaving -- those wait for tools/rust_vectors."""
+    import ctypes
+    import struct
+
+    import transcript_ref as T
+
+    tc1 = bytes.fromhex("9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f"
+                        "0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be")
+    assert b"".join(struct.pack("<I", w) for w in T.chacha_block([0] * 8, 0, rounds=12)) == tc1
+    seed = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)
+    assert T.StdRng(seed).next_u64() == 10719222850664546238
+    key20 = list(struct.unpack("<8I", bytes([0] * 8 + [1] + [0] * 7 + [2] + [0] * 7 + [3] + [0] * 7)))
+    assert T.chacha_block(key20, 0, rounds=20)[0] == 137206642
+    # the native generator
+    shim = ctypes.CDLL(os.path.join(ROOT, "tests", "cpp", "libff_host_shim.so"))
+    out = (ctypes.c_uint64 * 8)()
+    shim.shim_stdrng_words((ctypes.c_uint32 * 8)(*[0] * 8), out, 8)
+    assert b"".join(struct.pack("<Q", v) for v in out) == tc1
+    shim.shim_stdrng_words((ctypes.c_uint32 * 8)(*struct.unpack("<8I", seed)), out, 1)
+    assert out[0] == 10719222850664546238
+    # the two statements agree on the seed expansion (no published vector): 8 seeds, all 8 key words
+    for state in (0, 1, 2, 3, 4, 8, 16, (1 << 64) - 1):
+        key = (ctypes.c_uint32 * 8)()
+        shim.shim_seed_from_u64(ctypes.c_uint64(state), key)
+        assert bytes(key) == T.seed_from_u64(state)

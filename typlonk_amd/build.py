@@ -70,7 +70,8 @@ def build_hip(force: bool = False) -> str:
 def build_host_shim(force: bool = False) -> str:
     src = os.path.join(ROOT, "tests", "cpp", "ff_host_shim.cpp")
     out = os.path.join(ROOT, "tests", "cpp", "libff_host_shim.so")
-    deps = [src, os.path.join(CSRC, "ff.hpp"), os.path.join(CSRC, "g1.hpp"), os.path.join(CSRC, "fq30.hpp"), os.path.join(CSRC, "g1_host64.hpp")]
+    deps = [src, os.path.join(CSRC, "ff.hpp"), os.path.join(CSRC, "g1.hpp"), os.path.join(CSRC, "fq30.hpp"), os.path.join(CSRC, "g1_host64.hpp"),
+            os.path.join(CSRC, "transcript.hpp")]
     if force or _stale(out, deps):
         _run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
     return out

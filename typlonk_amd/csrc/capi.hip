@@ -471,7 +471,10 @@ int evict_coset_tables(typlonk_ctx* ctx, const std::string& incoming_group, size
                 oldest = g.second.first;
                 victim = g.first;
             }
-        HIPCHK(hipStreamSynchronize(ctx->stream));  // kernels still reading the victim's tables
+        // kernels still reading the victim's tables: they may sit on a stream the context has since been moved away
+        // from (typlonk_set_stream) or come from an un-synchronised *_devptr call, so the rare eviction waits for the
+        // whole device rather than for the current stream only
+        HIPCHK(hipDeviceSynchronize());
         for (auto it = ctx->tables.begin(); it != ctx->tables.end();) {
             if (it->first.compare(0, victim.size(), victim) == 0 &&
                 (it->first.size() == victim.size() || it->first[victim.size()] == ':')) {
@@ -513,7 +516,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     uint32_t ks[4], P;
     // (not inside a prover round: there the 144 KiB workgroups crowd out the LDS of the MSM lanes' sort kernels running
     // beside them -- prove() 38.1 -> 38.3 ms in the same-box A/B)
-    bool big = ctx->ntt_big_tiles && log_n == 20 && ctx->prover_rounds_active == 0;
+    bool big = ctx->ntt_big_tiles && log_n == 20 && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
     if (big && ctx->ntt_fr30 == 2 && ctx->ntt_full_tables) big = false;  // 36 B per element: 4096 of them do not fit
     const uint32_t cap = big ? 12 : 10;        // log2 of the tile capacity
     const unsigned threads = big ? 1024 : 256;

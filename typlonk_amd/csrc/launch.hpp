@@ -68,6 +68,8 @@ void launch_lincomb(const LincombArgs& a, hipStream_t s);
 void launch_open_multi(const Fr* const* polys, Fr* const* quotients, Fr* const* ys, const uint8_t* zsel, uint32_t count,
                        uint64_t m, const Fr& z0, const Fr& z1, Fr* blocks, hipStream_t s);
 
+// can this device run the 4096-element tiles (144 KiB of dynamic LDS)?  false: the opt-in was refused -> 1024-element tiles
+bool ntt_big_tiles_available();
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);
 // the same pass on 9 x 30-bit limbs: every table in `a` is a full table in the 2^270 domain, 36 B of LDS per element
 void launch_ntt_pass30(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);

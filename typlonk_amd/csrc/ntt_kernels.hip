@@ -358,27 +358,26 @@ void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, u
     hipLaunchKernelGGL(ntt_full_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, h, S, n, out);
 }
 
+// More than the default 64 KiB of dynamic LDS needs an opt-in (gfx950 has 160 KiB per workgroup).  The attribute is
+// per DEVICE: a process may hold contexts on several (typlonk_init(device_ordinal)), so the flag is kept per device
+// ordinal, and a refusal is reported to the planner, which then stays with 1024-element tiles.
+static bool ntt_raise_lds(const void* kernel, int which) {
+    static int state[2][64] = {};   // 0 = not tried, 1 = raised, -1 = refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[which][dev] == 0)
+        state[which][dev] = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : -1;
+    if (state[which][dev] < 0) (void)hipGetLastError();
+    return state[which][dev] > 0;
+}
+bool ntt_big_tiles_available() { return ntt_raise_lds(reinterpret_cast<const void*>(ntt_pass_kernel), 0); }
+
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s) {
-    if (lds_bytes > 64 * 1024) {
-        // more than the default dynamic-LDS limit: opt in once (gfx950 has 160 KiB per workgroup)
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            raised = true;
-        }
-    }
+    if (lds_bytes > 64 * 1024) (void)ntt_raise_lds(reinterpret_cast<const void*>(ntt_pass_kernel), 0);
     hipLaunchKernelGGL(ntt_pass_kernel, dim3(blocks), dim3(threads), lds_bytes, s, a);
 }
 void launch_ntt_pass30(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s) {
-    if (lds_bytes > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass30_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            raised = true;
-        }
-    }
+    if (lds_bytes > 64 * 1024) (void)ntt_raise_lds(reinterpret_cast<const void*>(ntt_pass30_kernel), 1);
     hipLaunchKernelGGL(ntt_pass30_kernel, dim3(blocks), dim3(threads), lds_bytes, s, a);
 }
 

@@ -357,11 +357,46 @@ inline pairing::G1Aff to_pairing(const G1Point& p, bool negate = false) {
     a.infinity = p.infinity;
     return a;
 }
+// C - y * G on the host (g1_host64.hpp), G = the FIXED generator G1Point::prime_subgroup_generator() the reference's
+// verifier uses (kzg/src/lib.rs:76) -- not srs[0], which an Srs::from_points caller is free to choose --, with no device
+// round trip: a verifier that checks six openings does twelve double-and-add ladders on the host instead of six SRS
+// uploads + MSMs.
+inline G1Point g1_sub_y_times_generator(const G1Point& c, const Fr& y) {
+    namespace H = ty::h64;
+    // arkworks' Montgomery limbs of the generator (the constants pinned in tests/test_oracle.py)
+    static const uint64_t GEN[12] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull, 0xf0ae6acdf3d0e747ull,
+                                     0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull, 0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull,
+                                     0xdd595f13570725ceull, 0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
+    static const uint64_t ONE[6] = {0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull,
+                                    0x77ce585370525745ull, 0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull};   // R mod p
+    auto lift = [&](const uint64_t* xy) {
+        H::Xyzz r;
+        std::memcpy(r.x.v, xy, 48);
+        std::memcpy(r.y.v, xy + 6, 48);
+        std::memcpy(r.zz.v, ONE, 48);
+        std::memcpy(r.zzz.v, ONE, 48);
+        return r;
+    };
+    const ty::Fr k = ty::fe_from_mont(ty::fe_neg(y.v));   // canonical -y
+    const H::Xyzz g = lift(GEN);
+    H::Xyzz acc = H::inf();
+    for (int w = 7; w >= 0; --w)
+        for (int b = 31; b >= 0; --b) {
+            acc = H::xyzz_dbl(acc);
+            if ((k.v[w] >> b) & 1u) acc = H::xyzz_add(acc, g);
+        }
+    if (!c.infinity) acc = H::xyzz_add(acc, lift(c.xy));
+    G1Point out;
+    out.infinity = !H::xyzz_to_affine(acc, out.xy);
+    if (out.infinity) {
+        std::memset(out.xy, 0, 48);
+        std::memcpy(out.xy + 6, ONE, 48);   // GroupAffine::zero() = (0, 1, infinity)
+    }
+    return out;
+}
 inline bool KzgScheme::verify(const KzgCommitment& commitment, const KzgOpening& opening, const Fr& z) const {
-    const Context& ctx = srs_.ctx();
     const pairing::G2Affine a = pairing::g2_add(srs_.g2s(), pairing::g2_neg(pairing::g2_mul(srs_.g2(), z.v)));
-    const G1Point g = srs_.g1_generator();
-    const G1Point b = g1_lincomb(ctx, {commitment.p, g}, {Fr::one(), -opening.y});  // C - y G1
+    const G1Point b = g1_sub_y_times_generator(commitment.p, opening.y);  // C - y G1
     const pairing::G1Aff ps[2] = {to_pairing(opening.p), to_pairing(b, /*negate=*/true)};
     const pairing::G2Affine qs[2] = {a, srs_.g2()};
     return pairing::pairing_product_is_one(ps, qs, 2);
