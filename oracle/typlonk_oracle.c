@@ -558,3 +558,139 @@ int oracle_ntt_mt(uint64_t* data, uint32_t log_n, int inverse, const uint64_t* c
     }
     return 0;
 }
+
+/* ======================================================================================================
+ * "FAIR CPU" PROVER KERNELS (bench.py cpu_fair.prove_ms, oracle/cpu_prover.py) -- test infrastructure.
+ * What a competent CPU implementation of plonk::proof::prove (/root/reference/plonk/src/proof.rs:96-194) would use
+ * instead of the reference's asymptotically slow steps, on all cores: NTT-based quotient on the 4n coset instead of
+ * twelve schoolbook products (:292-375), one batch inversion instead of 3n field divisions in the grand product
+ * (permutation/src/proving.rs:7-31), bucket-method MSMs (oracle_msm_pippenger).  Same field, same formulas, same
+ * results bit for bit as the reference path and the GPU path (checked in bench.py and tests/test_oracle.py).
+ * ====================================================================================================== */
+/* out = constant + sum_k scalars[k] * polys[k]   (n coefficients each; constant may be NULL) */
+int oracle_fr_lincomb(const uint64_t* const* polys, const uint64_t* scalars, size_t k, size_t n, const uint64_t* constant,
+                      uint64_t* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        fr acc = {{0, 0, 0, 0}};
+        if (constant && i == 0) memcpy(acc.v, constant, 32);
+        for (size_t j = 0; j < k; ++j) {
+            fr t; fr_mul(&t, (const fr*)(polys[j] + 4 * i), (const fr*)(scalars + 4 * j));
+            fr_add(&acc, &acc, &t);
+        }
+        memcpy(out + 4 * i, acc.v, 32);
+    }
+    return 0;
+}
+
+/* Z over the domain: Z_0 = 1, Z_{j+1} = Z_j * prod_i (w_ij + beta k_i w^j + gamma) / (w_ij + beta sigma_ij + gamma).
+ * Chunked: per chunk the denominators are inverted with one field inversion (Montgomery's trick), then a two-pass
+ * prefix product.  Returns the n values Z_0..Z_{n-1}; *last = Z_n (must be 1 for a satisfied permutation). */
+int oracle_grand_product(const uint64_t* const wires[3], const uint64_t* const sigma[3], const uint64_t beta_m[4],
+                         const uint64_t gamma_m[4], const uint64_t k_m[3][4], uint32_t log_n, uint64_t* z_out, uint64_t last[4]) {
+    const int64_t n = (int64_t)1 << log_n;
+    fr beta, gamma, root, kk[3];
+    memcpy(beta.v, beta_m, 32); memcpy(gamma.v, gamma_m, 32);
+    for (int i = 0; i < 3; ++i) memcpy(kk[i].v, k_m[i], 32);
+    fr_to_mont(&root, R_ROOT_CANON);
+    for (uint32_t i = log_n; i < 32; ++i) fr_mul(&root, &root, &root);
+    fr* ratio = (fr*)malloc((size_t)n * sizeof(fr));
+    if (!ratio) return -2;
+    const int64_t CH = 2048;
+    const int64_t nch = (n + CH - 1) / CH;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nch; ++c) {
+        const int64_t lo = c * CH, hi = lo + CH < n ? lo + CH : n;
+        fr num[2048], den[2048], pre[2048];
+        fr w; fr_pow_u64(&w, &root, (uint64_t)lo);
+        fr run; memcpy(run.v, R_ONE, 32);
+        for (int64_t j = lo; j < hi; ++j) {
+            fr nu, de; memcpy(nu.v, R_ONE, 32); memcpy(de.v, R_ONE, 32);
+            for (int i = 0; i < 3; ++i) {
+                fr wv, t, u; memcpy(wv.v, wires[i] + 4 * j, 32);
+                fr_mul(&t, &kk[i], &w); fr_mul(&t, &t, &beta); fr_add(&t, &t, &wv); fr_add(&t, &t, &gamma); fr_mul(&nu, &nu, &t);
+                memcpy(u.v, sigma[i] + 4 * j, 32); fr_mul(&u, &u, &beta); fr_add(&u, &u, &wv); fr_add(&u, &u, &gamma); fr_mul(&de, &de, &u);
+            }
+            num[j - lo] = nu; den[j - lo] = de; pre[j - lo] = run; fr_mul(&run, &run, &de);
+            fr_mul(&w, &w, &root);
+        }
+        fr inv; fr_inv(&inv, &run);
+        for (int64_t j = hi - 1; j >= lo; --j) {
+            fr dinv; fr_mul(&dinv, &inv, &pre[j - lo]); fr_mul(&inv, &inv, &den[j - lo]);
+            fr_mul(&ratio[j], &num[j - lo], &dinv);
+        }
+    }
+    /* prefix product: chunk totals, then the running products */
+    fr* tot = (fr*)malloc((size_t)nch * sizeof(fr));
+    if (!tot) { free(ratio); return -2; }
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nch; ++c) {
+        const int64_t lo = c * CH, hi = lo + CH < n ? lo + CH : n;
+        fr p; memcpy(p.v, R_ONE, 32);
+        for (int64_t j = lo; j < hi; ++j) fr_mul(&p, &p, &ratio[j]);
+        tot[c] = p;
+    }
+    fr run; memcpy(run.v, R_ONE, 32);
+    for (int64_t c = 0; c < nch; ++c) { fr t = tot[c]; tot[c] = run; fr_mul(&run, &run, &t); }
+    memcpy(last, run.v, 32);
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nch; ++c) {
+        const int64_t lo = c * CH, hi = lo + CH < n ? lo + CH : n;
+        fr p = tot[c];
+        for (int64_t j = lo; j < hi; ++j) { memcpy(z_out + 4 * j, p.v, 32); fr_mul(&p, &p, &ratio[j]); }
+    }
+    free(tot); free(ratio);
+    return 0;
+}
+
+/* The quotient on the coset g H_4n, pointwise (g = 7): ev[k] = the 4n coset evaluations of, in this order,
+ *   a b c Z PI q_l q_r q_o q_m q_c sigma_0 sigma_1 sigma_2 L0
+ * t(x) = [gate + alpha (lhs - rhs) + alpha^2 (Z - 1) L0] / (x^n - 1), Z(w x) = the evaluation four indices further.
+ * (plonk/src/proof.rs:317-364 evaluated pointwise; x^n - 1 takes four values on this coset.) */
+int oracle_quotient_pointwise(const uint64_t* const ev[14], uint32_t log_n, const uint64_t alpha_m[4], const uint64_t beta_m[4],
+                              const uint64_t gamma_m[4], const uint64_t k_m[3][4], const uint64_t g_m[4], uint64_t* out) {
+    const int64_t n = (int64_t)1 << log_n, n4 = 4 * n;
+    fr alpha, alpha2, beta, gamma, g, kk[3], w4, one;
+    memcpy(alpha.v, alpha_m, 32); memcpy(beta.v, beta_m, 32); memcpy(gamma.v, gamma_m, 32); memcpy(g.v, g_m, 32);
+    memcpy(one.v, R_ONE, 32);
+    fr_mul(&alpha2, &alpha, &alpha);
+    for (int i = 0; i < 3; ++i) memcpy(kk[i].v, k_m[i], 32);
+    fr_to_mont(&w4, R_ROOT_CANON);
+    for (uint32_t i = log_n + 2; i < 32; ++i) fr_mul(&w4, &w4, &w4);
+    /* 1 / (x^n - 1) for x = g w4^i: x^n = g^n * (w4^n)^i, w4^n = a primitive 4th root */
+    fr gn, i4, zh_inv[4];
+    fr_pow_u64(&gn, &g, (uint64_t)n);
+    fr_pow_u64(&i4, &w4, (uint64_t)n);
+    { fr p = gn; for (int r = 0; r < 4; ++r) { fr d; fr_sub(&d, &p, &one); fr_inv(&zh_inv[r], &d); fr_mul(&p, &p, &i4); } }
+    const int64_t CH = 4096;
+#pragma omp parallel for schedule(static)
+    for (int64_t c0 = 0; c0 < n4; c0 += CH) {
+        fr x; fr_pow_u64(&x, &w4, (uint64_t)c0); fr_mul(&x, &x, &g);
+        for (int64_t i = c0; i < c0 + CH && i < n4; ++i) {
+#define EV(k, idx) ((const fr*)(ev[k] + 4 * (idx)))
+            const fr *a = EV(0, i), *b = EV(1, i), *cc = EV(2, i), *z = EV(3, i), *pi = EV(4, i);
+            const fr* zw = EV(3, (i + 4) % n4);
+            fr gate, t, u;
+            fr_mul(&gate, EV(5, i), a);
+            fr_mul(&t, EV(6, i), b); fr_add(&gate, &gate, &t);
+            fr_mul(&t, EV(7, i), cc); fr_sub(&gate, &gate, &t);
+            fr_mul(&t, EV(8, i), a); fr_mul(&t, &t, b); fr_add(&gate, &gate, &t);
+            fr_add(&gate, &gate, EV(9, i)); fr_add(&gate, &gate, pi);
+            fr lhs = *z, rhs = *zw, bx;
+            fr_mul(&bx, &beta, &x);
+            const fr* wv[3] = {a, b, cc};
+            for (int k = 0; k < 3; ++k) {
+                fr_mul(&t, &kk[k], &bx); fr_add(&t, &t, wv[k]); fr_add(&t, &t, &gamma); fr_mul(&lhs, &lhs, &t);
+                fr_mul(&u, EV(10 + k, i), &beta); fr_add(&u, &u, wv[k]); fr_add(&u, &u, &gamma); fr_mul(&rhs, &rhs, &u);
+            }
+            fr perm; fr_sub(&perm, &lhs, &rhs); fr_mul(&perm, &perm, &alpha);
+            fr l4; fr_sub(&l4, z, &one); fr_mul(&l4, &l4, EV(13, i)); fr_mul(&l4, &l4, &alpha2);
+            fr_add(&gate, &gate, &perm); fr_add(&gate, &gate, &l4);
+            fr_mul(&gate, &gate, &zh_inv[i & 3]);
+            memcpy(out + 4 * i, gate.v, 32);
+            fr_mul(&x, &x, &w4);
+#undef EV
+        }
+    }
+    return 0;
+}

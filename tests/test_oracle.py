@@ -259,3 +259,34 @@ def test_front_end_oracle_reproduces_kat5():
     assert F.witness(readme, [3, 4, 5]) == ([3, 4, 5, 9], [3, 4, 5, 16], [9, 16, 25, 25])
     with pytest.raises(ValueError):
         F.compile_circuit(lambda v: v[0].assert_eq(v[1]), 2)
+
+
+@pytest.mark.parametrize("log_n", [3, 5])
+def test_fair_cpu_prover_equals_the_reference_shaped_oracle(log_n):
+    """oracle/cpu_prover.py (NTT quotient, batch-inverted grand product, bucket MSMs, all cores: bench.py's cpu_fair leg)
+    returns exactly the proof oracle/plonk_oracle.py's restatement of prove() returns (schoolbook quotient, one division
+    per cell, per-term MSM): the two CPU paths the bench times are the same function"""
+    import numpy as np
+
+    from helpers import fr_pack, g1_pack, g1_unpack_one
+    from oracle import cpu_prover as CP
+    from oracle import plonk_oracle as PO
+
+    n, cols, q_evals, perm = PO.squaring_chain(log_n)
+    _, sig = PO.compile_permutation(perm, n, log_n)
+    secret = 0x1D0C5EED
+    srs = O.srs_from_secret(secret, n)            # n + 3 points
+    alpha, beta, gamma, zeta = 0x1234567DEADBEEF, 0xABCDEF0123456789ABCDEF, 0x55AA55AA77, 0x0F1E2D3C4B5A6978
+    ref = PO.prove(log_n, cols, q_evals, perm, [0] * n, (alpha, beta, gamma), zeta, lambda p: O.kzg_commit(srs, p))
+    inputs = {"wires": [fr_pack(c) for c in cols], "selectors": [fr_pack(q_evals[k]) for k in ("q_l", "q_r", "q_o", "q_m", "q_c")],
+              "sigma": [fr_pack(s) for s in sig], "cosets": PO.COSETS}
+    xy, inf = g1_pack(srs)
+    lim = lambda v: np.array(O.fr_to_mont_limbs(v), dtype=np.uint64)   # noqa: E731
+    got = CP.prove(log_n, inputs, xy, inf, [lim(beta), lim(gamma), lim(alpha), lim(zeta)])
+    pt = lambda t: g1_unpack_one(t[0], t[1])                            # noqa: E731
+    fr = lambda a: O.fr_from_mont_limbs([int(x) for x in a])            # noqa: E731
+    assert [pt(c) for c in got["commit"]] == ref["commit"] and pt(got["z_commit"]) == ref["z_commit"]
+    assert [pt(c) for c in got["t_commit"]] == ref["t_commit"]
+    opens = ref["open"] + [ref["z_open"], ref["zw_open"], ref["r_open"]]
+    assert [pt(w) for w in got["witness"]] == [o[0] for o in opens]
+    assert [fr(e) for e in got["evals"]] == [o[1] for o in opens] and fr(got["evals"][5]) == 0

@@ -83,10 +83,35 @@ class ShardedMsm:
         if dist.is_initialized() and dist.get_backend(group) == "nccl" and (world > 1 or self.force_collective) \
                 and os.environ.get("TYPLONK_NATIVE_COMM", "1") != "0":
             from .capi import comm_unique_id
-            box = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=group, device=device)
-            ctx.comm_init(box[0], rank, world)
-            self.native = True
+            # A rank on which the native communicator cannot come up must not leave the others inside a collective of
+            # a communicator it is not part of: every step is agreed on by all ranks (MIN over a flag), and if any rank
+            # failed, all of them fall back to the torch.distributed exchange below.
+            def agree(ok: bool) -> bool:
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                return bool(t.item())
+
+            box, err = [None], None
+            try:
+                if rank == 0:
+                    box[0] = comm_unique_id()
+            except Exception as e:  # noqa: BLE001 -- librccl missing: reported, not fatal
+                err = e
+            if agree(err is None):
+                dist.broadcast_object_list(box, src=0, group=group, device=device)
+                try:
+                    ctx.comm_init(box[0], rank, world)
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                if agree(err is None):
+                    self.native = True
+                else:
+                    try:
+                        ctx.comm_destroy()
+                    except Exception:  # noqa: BLE001
+                        pass
+            if not self.native and rank == 0:
+                print(f"typlonk_amd.dist: native RCCL exchange unavailable ({err}); using torch.distributed", flush=True)
 
     def generate_srs(self, secret_limbs):
         """build only this rank's slice [s^lo G, ..., s^(hi-1) G] in HBM"""
