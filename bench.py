@@ -64,6 +64,7 @@ MIXED_ADD_ALL_VALU_MODEL = float(_isa("r03_isa_msm_accum.json", "ceiling_units_p
 # the same for one Fr multiplication inside the NTT butterflies (tools/isa_count.py on ntt_kernels.hip; 64 v_mad_u64_u32
 # of the product scan + 64 of the reduction = 128 per multiplication -> 1024 * 64 / (128 * 2.19 ns) = 234 G/s)
 FR_MUL_MULTIPLIER_CEILING = float(_isa("r03_isa_ntt.json", "ceiling_fr_mul_per_s_multiplier_only", 1024 * 64 / (128 * 5.26 / 2.4e9)))
+FR_MUL_ALL_VALU_MODEL = float(_isa("r03_isa_ntt.json", "ceiling_fr_mul_per_s_all_valu", 1.077e11))
 
 
 def fr_mont_limbs(x: int) -> np.ndarray:
@@ -302,7 +303,8 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
                     "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, "
                                       "bytes per launch)"},
             "hbm_frac": ach / HBM_PEAK_GBS,
-            "note": "integer-VALU-bound (91 % of the issue slots at 2.06 GHz, profiles/r02_pmc_sq_valu_msm.json); the HBM "
+            "sq_valu_util": _isa("r03_pmc_sq_valu_msm.json", "ty::msm_accum_kernel grid=524288", {}).get("valu_util"),
+            "note": "integer-VALU-bound (91 % of the issue slots at 2.17 GHz, profiles/r03_pmc_sq_valu_msm.json); the HBM "
                     "fraction the north-star asks for is kept as hbm_frac -- see DESIGN.md section 4"}
 
     if rank == 0 and not args.msm_only:
@@ -359,8 +361,13 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
                      "algorithmic_GBps": 64.0 * n / kern_s / 1e9, "frac_of_hbm_peak": 64.0 * n / kern_s / 1e9 / HBM_PEAK_GBS,
                      "valu": {"achieved": fr_muls / kern_s, "peak": FR_MUL_MULTIPLIER_CEILING, "unit": "Fr mul/s",
                               "frac": fr_muls / kern_s / FR_MUL_MULTIPLIER_CEILING,
-                              "peak_source": "128 v_mad_u64_u32 per Fr multiplication x 2.19 ns x 1024 SIMDs x 64 lanes "
-                                             "(multiplier instructions only)"}}
+                              "fr_mul_per_transform": fr_muls,
+                              "peak_source": "128 v_mad_u64_u32 per Fr multiplication (profiles/r03_isa_ntt.json) x 2.19 ns x "
+                                             "1024 SIMDs x 64 lanes (multiplier instructions only)",
+                              "all_valu_model": {"peak": FR_MUL_ALL_VALU_MODEL, "frac": fr_muls / kern_s / FR_MUL_ALL_VALU_MODEL,
+                                                 "note": "all 1455 VALU instructions of a radix-4 group (4 multiplications, 8 "
+                                                         "additions / subtractions, addressing) priced with their own issue times"},
+                              "sq_valu_util": _isa("r03_pmc_sq_valu_ntt.json", "ty::ntt_pass_kernel grid=%d" % (n // 4), {}).get("valu_util")}}
     for name in ("r03_pmc_ntt.json", "r02_pmc_ntt.json"):   # PMC traffic of one pass
         pm = _isa(name, f"ntt_pass_kernel n=2^{log_n}", None)
         if pm:

@@ -52,15 +52,25 @@ out["local_msm_wall_noprof_ms"] = round((time.perf_counter() - t0) / reps * 1e3,
 if os.environ.get("NO_EXCHANGE") == "1":
     print("SHARD " + json.dumps(out))
     sys.exit(0)
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29533")
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+# the exchange behind the C ABI on a one-rank communicator (RCCL all-gather of 104-B records + host fold): the launch,
+# copy and synchronisation latencies of the real thing, no wire time
+from typlonk_amd.capi import comm_unique_id
+ctx.comm_init(comm_unique_id(), 0, 1)
 for _ in range(10):
-    allgather_fold(xy, inf, dev)
+    ctx.comm_fold([(xy, inf)])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
-    allgather_fold(xy, inf, dev)
-out["exchange_fold_ms_one_rank_group"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    ctx.comm_fold([(xy, inf)])
+out["native_fold_1_point_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+t0 = time.perf_counter()
+for _ in range(reps):
+    ctx.comm_fold([(xy, inf)] * 9)
+out["native_fold_9_points_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+for _ in range(10):
+    ctx.msm_sharded_devptr(sh.sid, full.data_ptr(), n)
+t0 = time.perf_counter()
+for _ in range(reps):
+    ctx.msm_sharded_devptr(sh.sid, full.data_ptr(), n)
+out["sharded_msm_wall_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
 print("SHARD " + json.dumps(out))
-dist.destroy_process_group()

@@ -166,28 +166,33 @@ __global__ __launch_bounds__(64) void msm_rc_final_kernel(const uint32_t* __rest
 //   2. msm_rc2_planes_kernel  one workgroup per (set, kind, weight bit): the partials of the items whose weight has
 //                             that bit set are butterfly-summed per wavefront, then across the wavefronts through LDS.
 // Same bit planes out as msm_rc_final_kernel (the host finish does not change).
-__global__ __launch_bounds__(64) void msm_rc2_sums_kernel(const uint32_t* __restrict__ buckets, RcShape sh, uint32_t sr,
-                                                          uint32_t sc, uint32_t nwave_row, uint32_t* prow, uint32_t* pcol) {
+// (workgroups of four wavefronts: one per SIMD of a CU.  With one-wavefront workgroups the dispatcher was seen to stack
+// two of the 1024 wavefronts on one SIMD and leave another idle, 112 us instead of 76.)
+__global__ __launch_bounds__(256) void msm_rc2_sums_kernel(const uint32_t* __restrict__ buckets, RcShape sh, uint32_t sr,
+                                                           uint32_t sc, uint32_t nwave_row, uint32_t nwave, uint32_t* prow,
+                                                           uint32_t* pcol) {
+    const uint32_t wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (wv >= nwave) return;   // whole wavefronts only
     G1Xyzz v;
-    if (blockIdx.x < nwave_row) {
-        const uint64_t base = ((uint64_t)blockIdx.x * 64 + threadIdx.x) << sr;   // a run never leaves its row: 64 * 2^sr | C
+    if (wv < nwave_row) {
+        const uint64_t base = ((uint64_t)wv * 64 + lane) << sr;   // a run never leaves its row: 64 * 2^sr | C
         v = ld_xyzz(buckets, base);
         for (uint32_t i = 1; i < (1u << sr); ++i) v = g1_add(v, ld_xyzz(buckets, base + i));
     } else {
-        const uint32_t u = blockIdx.x - nwave_row;
+        const uint32_t u = wv - nwave_row;
         const uint32_t lpc = sh.ch - 6 - sc;                                      // log2 partials per column
         const uint32_t rchunk = u & ((1u << lpc) - 1), col = u >> lpc;            // col = set << cl | lo
         const uint32_t set = col >> sh.cl, lo = col & ((1u << sh.cl) - 1);
-        const uint32_t row0 = ((rchunk * 64 + threadIdx.x) << sc);
+        const uint32_t row0 = ((rchunk * 64 + lane) << sc);
         const uint64_t first = ((uint64_t)set << sh.c1) + ((uint64_t)row0 << sh.cl) + lo;
         v = ld_xyzz(buckets, first);
         for (uint32_t i = 1; i < (1u << sc); ++i) v = g1_add(v, ld_xyzz(buckets, first + ((uint64_t)i << sh.cl)));
     }
 #pragma unroll 1
     for (int mask = 1; mask < 64; mask <<= 1) v = butterfly_add(v, mask);
-    if (threadIdx.x == 0) {
-        if (blockIdx.x < nwave_row) st_xyzz(prow, blockIdx.x, v);
-        else st_xyzz(pcol, blockIdx.x - nwave_row, v);
+    if (lane == 0) {
+        if (wv < nwave_row) st_xyzz(prow, wv, v);
+        else st_xyzz(pcol, wv - nwave_row, v);
     }
 }
 
@@ -247,8 +252,8 @@ void launch_msm_rc2_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t*
     const uint32_t want = lnb > 15 ? lnb - 15 : 0;            // ~1024 wavefronts in the first launch
     const uint32_t sr = want < sh.cl - 6 ? want : sh.cl - 6, sc = want < sh.ch - 6 ? want : sh.ch - 6;
     const uint32_t nwave_row = sh.nsets << (sh.c1 - 6 - sr), nwave_col = sh.nsets << (sh.c1 - 6 - sc);
-    hipLaunchKernelGGL(msm_rc2_sums_kernel, dim3(nwave_row + nwave_col), dim3(64), 0, s, buckets, sh, sr, sc, nwave_row, prow,
-                       pcol);
+    hipLaunchKernelGGL(msm_rc2_sums_kernel, dim3((nwave_row + nwave_col + 3) / 4), dim3(256), 0, s, buckets, sh, sr, sc, nwave_row,
+                       nwave_row + nwave_col, prow, pcol);
     const uint32_t lpr = sh.cl - 6 - sr, lpc = sh.ch - 6 - sc;
     const uint32_t np = 1u << ((sh.ch + lpr) > (sh.cl + lpc) ? (sh.ch + lpr) : (sh.cl + lpc));
     const uint32_t threads = np < 64 ? 64u : (np > (uint32_t)RC2_THREADS ? (uint32_t)RC2_THREADS : np);
