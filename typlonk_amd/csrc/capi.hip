@@ -187,6 +187,8 @@ struct typlonk_ctx {
     // bit 2 = first opening MSMs of round 3 submitted before the quotient
     int prover_overlap = 3;   // measured (profiles/r02_ab_prover_overlap.txt): bits 0-1 gain ~1 %, bit 2 loses ~1 %
     int msm_chunks = 0;            // TYPLONK_MSM_CHUNKS: chunks of a stand-alone MSM (0 = choose by length)
+    bool msm_side_prio = false;    // TYPLONK_MSM_SIDE_PRIO=1: the side stream of the chunk sorts at the highest stream priority
+                                   // (measured: no effect -- 2.61-2.65 ms either way, profiles/r03_side_prio.txt)
     bool msm_stagger = true;       // TYPLONK_MSM_STAGGER=0: the second chunk's sort runs beside the first one's (round-2 order)
     int msm_lanes = 0;             // TYPLONK_MSM_LANES: lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_rc4 = false;          // TYPLONK_MSM_REDUCE=rc4: always the four-launch row/column reduction (round-2 form)
@@ -827,7 +829,16 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     hipStream_t s = ws.stream;
     int rc;
     if (nch > 1) {
-        if (!ws.side) HIPCHK(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
+        if (!ws.side) {
+            // the side stream carries the sorts of the chunks after the first: short, latency-bound kernels beside an
+            // accumulation that fills every wavefront slot.  A high stream priority (TYPLONK_MSM_SIDE_PRIO=1) was tried to
+            // get them dispatched as slots retire: no measurable effect, so the default stays a plain stream
+            int lo = 0, hi = 0;
+            if (ctx->msm_side_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+                HIPCHK(hipStreamCreateWithPriority(&ws.side, hipStreamNonBlocking, hi));
+            else
+                HIPCHK(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
+        }
         if (!ws.ev_in) HIPCHK(hipEventCreateWithFlags(&ws.ev_in, hipEventDisableTiming));
         for (uint32_t k = 0; k < nch; ++k) {
             if (!ws.ev_sorted[k]) HIPCHK(hipEventCreateWithFlags(&ws.ev_sorted[k], hipEventDisableTiming));
@@ -887,7 +898,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             if ((rc = ensure(ctx, sb.blk_base, (seg.nmat + 1) * 4))) return rc;
             if ((rc = ensure(ctx, sb.blocksums, (size_t)((seg.nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks + seg.nseg) * 4))) return rc;
             blocksums = (uint32_t*)sb.blocksums.p;
-            StageTimer st(ctx, "msm_sort", ss);
+            StageTimer st(ctx, ss == s ? "msm_sort" : "msm_sort_overlapped", ss);
             launch_msm_segsort(sc, (uint64_t)mk, c, W, digit_v, (uint32_t)seg.hb, seg.ibits, tables ? (uint32_t)srs.len : 0u,
                                tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums, keys,
                                counts, offsets, sorted, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p,
@@ -1334,6 +1345,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         ctx->msm_rc2_force = (strcmp(e, "rc2") == 0);
     }
     if (const char* e = getenv("TYPLONK_MSM_STAGGER")) ctx->msm_stagger = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_MSM_SIDE_PRIO")) ctx->msm_side_prio = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
         const int l = atoi(e);
         if (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) ctx->msm_lanes = l;
