@@ -135,6 +135,13 @@ def test_a_2_22_row_circuit_is_proved_and_accepted_by_the_pairing_verifier(built
     assert "rows=4194304" in out and "all ok" in out
 
 
+@pytest.mark.gpu
+def test_rccl_exchange_from_a_plain_cpp_process(built):
+    """typlonk_comm_* / typlonk_msm_g1_sharded_* called from C++ with neither Python nor PyTorch in the process: the
+    library loads the system's librccl by itself (what a Rust host gets)"""
+    _run("test_comm_host")
+
+
 @pytest.mark.parametrize("name", ["test_poly_host", "test_circuit_tables_host"])
 def test_host_mirror_under_address_and_ub_sanitizers(built, tmp_path, name):
     """the host-side C++ (typlonk_host.hpp, circuit_host.hpp + the shared field headers) compiled with ASan + UBSan on the

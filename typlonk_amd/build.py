@@ -84,7 +84,8 @@ def build_host_tests(force: bool = False) -> list[str]:
            os.path.join(ROOT, "tests", "cpp", "circuit_host.hpp"),
            os.path.join(CSRC, "ff.hpp"), os.path.join(CSRC, "fq30.hpp"), os.path.join(CSRC, "g1_host64.hpp"),
            os.path.join(CSRC, "transcript.hpp"), LIB]
-    for name in ("test_poly_host", "test_kzg_host", "test_plonk_host", "test_pairing_host", "test_circuit_tables_host", "test_circuit_host"):
+    for name in ("test_poly_host", "test_kzg_host", "test_plonk_host", "test_pairing_host", "test_circuit_tables_host", "test_circuit_host",
+                 "test_comm_host"):
         src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
         out = os.path.join(ROOT, "tests", "cpp", name)
         if force or _stale(out, [src] + hdr):
