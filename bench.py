@@ -146,7 +146,7 @@ def main() -> None:
                     help="N > 1: skip the extra measurement of prove() with every MSM sharded over the ranks")
     ap.add_argument("--tables", default="auto",
                     help="fixed-base tables built once per SRS (shard): window bits 14..20, 'none', or 'auto' = 20 on one "
-                         "GPU, the library's choice by shard length (17 below 2^18 points) on several")
+                         "GPU, the library's choice by shard length (17 below 2^19 points) on several")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,7 +228,7 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
         tables_c = (20 if world == 1 else 0) if args.tables == "auto" else int(args.tables)
         ctx.srs_precompute(sh.sid, tables_c)
         if tables_c == 0:
-            tables_c = 17 if (sh.hi - sh.lo) < (1 << 18) else 20
+            tables_c = 17 if (sh.hi - sh.lo) < (1 << 19) else 20
 
     full = synthetic_scalars(n, 0x5EED0000 + log_n, device)
     lo, hi = local_range(n, srs_len, world, rank)

@@ -78,7 +78,7 @@ int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_
 /* Optional fixed-base precomputation (the SRS is immutable per circuit, plonk/src/lib.rs:22): builds the
  * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM -- 15 for c = 17 and 17 for
  * c = 15, which slice centred scalars |k| < 2^254 --, c = window_bits in 14..20, or 0 = chosen by length: 17 below
- * 2^18 points -- an index shard --, else 20, whose top window still has 15 bits).  Later MSMs of at least len/4
+ * 2^19 points -- an index shard --, else 20, whose top window still has 15 bits).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
  * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point.
  * An MSM length the table-mode sort cannot handle (more than 2^22 terms with 20-bit windows) silently takes the

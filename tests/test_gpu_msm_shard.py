@@ -108,7 +108,7 @@ def test_centred_tables_equal_the_reference_path_on_edge_scalars(ctx, c):
 @pytest.mark.parametrize("world,log_n", [(8, 20), (4, 20), (8, 22)])
 def test_index_shards_at_config_sizes_fold_to_the_commit_identity(ctx, world, log_n):
     """BASELINE config 4 / 5 shapes on one GPU: the 2^log_n-term commitment cut into `world` index shards, each with the
-    auto-chosen tables (typlonk_srs_precompute(0): c = 17 centred up to 2^18 points), multi-lane accumulation; the folded
+    auto-chosen tables (typlonk_srs_precompute(0): c = 17 centred below 2^19 points), multi-lane accumulation; the folded
     partial sums equal [p(s)]G (kzg/src/lib.rs:102-105) and the unsharded table-mode MSM"""
     from oracle import coracle as CO
     from typlonk_amd.capi import g1_sum_host

@@ -190,6 +190,7 @@ struct typlonk_ctx {
     bool msm_side_prio = false;    // TYPLONK_MSM_SIDE_PRIO=1: the side stream of the chunk sorts at the highest stream priority
                                    // (measured: no effect -- 2.61-2.65 ms either way, profiles/r03_side_prio.txt)
     bool msm_stagger = true;       // TYPLONK_MSM_STAGGER=0: the second chunk's sort runs beside the first one's (round-2 order)
+    bool msm_lanes_split = true;   // TYPLONK_MSM_LANES_SPLIT=0: one lane count for every bucket
     int msm_lanes = 0;             // TYPLONK_MSM_LANES: lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_rc4 = false;          // TYPLONK_MSM_REDUCE=rc4: always the four-launch row/column reduction (round-2 form)
     bool msm_rc2_force = false;    // TYPLONK_MSM_REDUCE=rc2: the two-launch form for every bucket-set size
@@ -941,9 +942,12 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
                 while (lanes < 16 && nb_used * lanes < (1u << 18)) lanes *= 2;
                 while (lanes > 1 && mean / lanes < 4) lanes /= 2;
             }
+            // two size classes (the larger half of the buckets: `lanes`, the smaller half: lanes / 2) when lanes were
+            // chosen from the load; TYPLONK_MSM_LANES forces one class, TYPLONK_MSM_LANES_SPLIT=0 switches the split off
+            const uint32_t split = (lanes >= 2 && !ctx->msm_lanes && ctx->msm_lanes_split) ? (uint32_t)(nb_used / 2) : (uint32_t)nb_used;
             StageTimer st(ctx, "msm_accum", s);
             launch_msm_accum(pts, offsets, sorted, (const uint32_t*)sb.order.p, (uint32_t)nb_used, cap, /*init=*/k > 0, lanes,
-                             buckets, s);
+                             split, buckets, s);
             launch_msm_heavy(pts, sorted, (uint32_t*)sb.ohist.p, (const uint32_t*)sb.heavy.p,
                              (const uint32_t*)sb.tasks.p, (uint32_t*)sb.hpart.p, buckets, s);
         }
@@ -1346,6 +1350,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     }
     if (const char* e = getenv("TYPLONK_MSM_STAGGER")) ctx->msm_stagger = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_SIDE_PRIO")) ctx->msm_side_prio = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_MSM_LANES_SPLIT")) ctx->msm_lanes_split = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
         const int l = atoi(e);
         if (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) ctx->msm_lanes = l;
@@ -1494,7 +1499,7 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     auto it = ctx->srs.find(srs_id);
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
-    if (window_bits == 0) window_bits = it->second.len < (1u << 18) ? 17 : 20;   // measured best: DESIGN.md section 6
+    if (window_bits == 0) window_bits = it->second.len < (1u << 19) ? 17 : 20;   // measured best: DESIGN.md section 6
     if (window_bits < 14 || window_bits > 20) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "window_bits must be 0 (auto) or 14..20");
     SrsEntry& e = it->second;
     if (e.table_T) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "tables already built for this SRS");

@@ -100,9 +100,11 @@ void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, uint32_t* 
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s);
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
                         hipStream_t s);
-// lanes = 1, 2, 4, 8, 16: lanes per bucket (msm_accum_kernel / msm_accum_ml_kernel<L>)
+// lanes = 1, 2, 4, 8, 16: lanes per bucket (msm_accum_kernel / msm_accum_ml_kernel<L>); the first `split` buckets of the
+// schedule (the larger ones) get `lanes`, the others lanes / 2 (split >= nbuckets: all get `lanes`)
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
-                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t lanes, uint32_t* buckets, hipStream_t s);
+                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t lanes, uint32_t split, uint32_t* buckets,
+                      hipStream_t s);
 void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
                        uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s);
 void launch_msm_fold(const uint32_t* in, uint32_t total, uint32_t group, uint32_t* out, hipStream_t s);

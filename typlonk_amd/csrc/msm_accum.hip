@@ -71,9 +71,15 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_ml_kernel(const uin
                                                                        const uint32_t* __restrict__ sorted,
                                                                        const uint32_t* __restrict__ order,
                                                                        uint32_t nbuckets, uint32_t cap, uint32_t init,
-                                                                       uint32_t* buckets) {
+                                                                       uint32_t split, uint32_t* buckets) {
+    // Two size classes: the schedule is sorted by population, so slots [0, split) -- the larger buckets -- get L lanes and
+    // the rest L / 2 (split = nbuckets: one class).  split * L is a multiple of the workgroup size: a workgroup, and
+    // with it every wavefront, is in one class.  Half the buckets at half the lanes save a third of the butterfly work.
     const uint32_t t = blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
-    const uint32_t slot = t / L, lane = t % L;
+    const uint32_t ta = split * L;
+    const uint32_t lanes = t < ta ? (uint32_t)L : (uint32_t)(L > 1 ? L / 2 : 1);
+    const uint32_t t2 = t < ta ? t : t - ta;
+    const uint32_t slot = (t < ta ? 0u : split) + t2 / lanes, lane = t2 % lanes;
     // every lane of the wavefront takes part in the butterfly: lanes past the last bucket carry the identity
     uint32_t g = 0, start = 0, end = 0;
     if (slot < nbuckets) {
@@ -90,17 +96,17 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_ml_kernel(const uin
         pl_next = sorted[pos];
         pk_next = ld_packed(points, pl_next & 0x7fffffffu);
     }
-    for (; pos < end; pos += L) {
+    for (; pos < end; pos += lanes) {
         const uint32_t pl = pl_next;
         const PackedPoint pk = pk_next;
-        if (pos + L < end) {
-            pl_next = sorted[pos + L];
+        if (pos + lanes < end) {
+            pl_next = sorted[pos + lanes];
             pk_next = ld_packed(points, pl_next & 0x7fffffffu);
         }
         g1_madd(acc, unpack_point(pk), (pl >> 31) != 0);
     }
 #pragma unroll 1
-    for (int mask = 1; mask < L; mask <<= 1) acc = butterfly_add(acc, mask);
+    for (int mask = 1; mask < (int)lanes; mask <<= 1) acc = butterfly_add(acc, mask);
     if (!skip && lane == 0) st_xyzz(buckets, g, acc);
 }
 
@@ -141,16 +147,23 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_kernel(const uint32
 }
 
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
-                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t lanes, uint32_t* buckets, hipStream_t s) {
-    const uint64_t threads = (uint64_t)nbuckets * (lanes ? lanes : 1u);
-    const dim3 grid((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), block(MSM_ACC_THREADS);
+                      uint32_t nbuckets, uint32_t cap, bool init, uint32_t lanes, uint32_t split, uint32_t* buckets,
+                      hipStream_t s) {
     const uint32_t in = init ? 1u : 0u;
+    if (lanes <= 1) {
+        const dim3 grid((nbuckets + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), block(MSM_ACC_THREADS);
+        hipLaunchKernelGGL(msm_accum_kernel, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets);
+        return;
+    }
+    // slots [0, split) with `lanes` lanes, the rest with lanes / 2; split * lanes must fill whole workgroups
+    split = split >= nbuckets ? nbuckets : split / (MSM_ACC_THREADS / lanes) * (MSM_ACC_THREADS / lanes);
+    const uint64_t threads = (uint64_t)split * lanes + (uint64_t)(nbuckets - split) * (lanes / 2);
+    const dim3 grid((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), block(MSM_ACC_THREADS);
     switch (lanes) {
-        case 2: hipLaunchKernelGGL(msm_accum_ml_kernel<2>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
-        case 4: hipLaunchKernelGGL(msm_accum_ml_kernel<4>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
-        case 8: hipLaunchKernelGGL(msm_accum_ml_kernel<8>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
-        case 16: hipLaunchKernelGGL(msm_accum_ml_kernel<16>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets); break;
-        default: hipLaunchKernelGGL(msm_accum_kernel, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, buckets);
+        case 2: hipLaunchKernelGGL(msm_accum_ml_kernel<2>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, split, buckets); break;
+        case 4: hipLaunchKernelGGL(msm_accum_ml_kernel<4>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, split, buckets); break;
+        case 8: hipLaunchKernelGGL(msm_accum_ml_kernel<8>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, split, buckets); break;
+        default: hipLaunchKernelGGL(msm_accum_ml_kernel<16>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, split, buckets); break;
     }
 }
 void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, uint32_t* hist516, const uint32_t* heavy,
