@@ -200,6 +200,7 @@ struct typlonk_ctx {
     int ntt_fr30 = 1;              // TYPLONK_NTT_FR30: 0 = off, 1 = 9 x 30-bit butterflies (fr30.hpp) up to 2^19,
                                    // 2 = for every transform (the 4096-element tiles of 2^20 are then not used)
     uint32_t ntt_full_max_log = 24;
+    bool ntt_direct = true;        // TYPLONK_NTT_DIRECT=0: the radix-4 groups all go through the LDS tile (staging copy in / out)
     bool ntt_radix4 = true;        // TYPLONK_NTT_RADIX=2: one LDS round trip per butterfly stage (the round-2 form)
     Comm comm;                     // typlonk_comm_init: RCCL communicator of this rank (world = 0: none)
     bool msm_legacy_sort = false;  // TYPLONK_MSM_SORT=atomic: per-entry global-atomic counting sort
@@ -623,7 +624,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         const uint64_t M = 1ull << k;
         const bool last = (p + 1 == P);
         NttPassArgs a{};
-        a.radix4 = ctx->ntt_radix4 ? 1u : 0u;
+        a.radix4 = ctx->ntt_radix4 ? (ctx->ntt_direct ? 2u : 1u) : 0u;
         a.k = k;
         a.last = last ? 1 : 0;
         a.S = row_len / M;
@@ -1363,6 +1364,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_NTT_FR30")) ctx->ntt_fr30 = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("TYPLONK_NTT_FULL_MAX_LOG")) ctx->ntt_full_max_log = (uint32_t)atoi(e);
     if (const char* e = getenv("TYPLONK_NTT_RADIX")) ctx->ntt_radix4 = atoi(e) != 2;
+    if (const char* e = getenv("TYPLONK_NTT_DIRECT")) ctx->ntt_direct = atoi(e) != 0;
     *out = ctx;
     return TYPLONK_OK;
 }

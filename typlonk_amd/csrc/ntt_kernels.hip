@@ -72,36 +72,49 @@ struct NttArith30 {
     static __device__ __forceinline__ E mul(const E& a, const E& b) { return fr30_mul(a, b); }
 };
 
-template <class A>
+// direct = true: the FIRST group takes its elements straight from global memory (gload(i, t): element (i, t) of the
+// tile, pre-factor applied) and the LAST group hands its results straight to gstore(i, t, y) (y = the value at in-tile
+// position i of the bit-reversed output; gstore applies the pass's closing factor and writes to global): the staging
+// copy into LDS, the copy out of it and two barriers per pass disappear.  i_fast: in the first group consecutive lanes
+// take consecutive i instead of consecutive t (the last pass reads rows of M contiguous elements).
+template <class A, class LoadG, class StoreG>
 __device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A::P stw, uint32_t k, uint32_t logT, uint32_t E,
-                                                  uint32_t tid, uint32_t nt) {
+                                                  uint32_t tid, uint32_t nt, bool direct, bool i_fast, LoadG gload, StoreG gstore) {
     using El = typename A::E;
     const uint32_t T = 1u << logT;
     uint32_t s = 0;
+    bool first = direct;
     if (k & 1u) {  // the odd stage first: half = 2^(k-1)
         const uint32_t lh = k - 1, half = 1u << lh;
         for (uint32_t qq = tid; qq < (E >> 1); qq += nt) {
-            const uint32_t t = qq & (T - 1), pos = qq >> logT;   // one butterfly per (pos, t): j < half, so pos = j
+            uint32_t t, pos;                                     // one butterfly per (pos, t): j < half, so pos = j
+            if (first && i_fast) { pos = qq & (half - 1); t = qq >> lh; }
+            else { t = qq & (T - 1); pos = qq >> logT; }
             const uint32_t ia = (pos << logT) + t, ib = ((pos + half) << logT) + t;
-            const El x = A::ld(tile, ia), y = A::ld(tile, ib);
+            const El x = first ? gload(pos, t) : A::ld(tile, ia), y = first ? gload(pos + half, t) : A::ld(tile, ib);
             A::st(tile, ia, A::add(x, y));
             const El d = A::sub(x, y);
             A::st(tile, ib, lh == 0 ? d : A::mul(d, A::ld(stw, pos)));
         }
         __syncthreads();
         s = 1;
+        first = false;
     }
     for (; s + 1 < k; s += 2) {
         const uint32_t lh = k - 1 - s;          // log2(half) of stage s, >= 1
         const uint32_t quarter = 1u << (lh - 1);
         const bool lastg = lh == 1;             // stages with half = 2, 1: low = 0
+        const bool out_direct = direct && lastg;
         for (uint32_t g = tid; g < (E >> 2); g += nt) {
-            const uint32_t t = g & (T - 1), rest = g >> logT;
+            uint32_t t, rest;
+            if (first && i_fast) { rest = g & ((1u << (k - 2)) - 1); t = g >> (k - 2); }
+            else { t = g & (T - 1); rest = g >> logT; }
             const uint32_t low = rest & (quarter - 1), hi = rest >> (lh - 1);
             const uint32_t i0 = (hi << (lh + 1)) + low;
             const uint32_t a0 = (i0 << logT) + t, a1 = a0 + (quarter << logT), a2 = a1 + (quarter << logT),
                            a3 = a2 + (quarter << logT);
-            const El x0 = A::ld(tile, a0), x1 = A::ld(tile, a1), x2 = A::ld(tile, a2), x3 = A::ld(tile, a3);
+            const El x0 = first ? gload(i0, t) : A::ld(tile, a0), x1 = first ? gload(i0 + quarter, t) : A::ld(tile, a1),
+                     x2 = first ? gload(i0 + 2 * quarter, t) : A::ld(tile, a2), x3 = first ? gload(i0 + 3 * quarter, t) : A::ld(tile, a3);
             const El s0 = A::add(x0, x2), s1 = A::add(x1, x3);
             El d0 = A::sub(x0, x2), d1 = A::sub(x1, x3);
             if (!lastg) {
@@ -116,12 +129,21 @@ __device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A
                 y1 = A::mul(y1, tw);
                 y3 = A::mul(y3, tw);
             }
-            A::st(tile, a0, A::add(s0, s1));
-            A::st(tile, a1, y1);
-            A::st(tile, a2, A::add(d0, d1));
-            A::st(tile, a3, y3);
+            const El y0 = A::add(s0, s1), y2 = A::add(d0, d1);
+            if (out_direct) {
+                gstore(i0, t, y0);
+                gstore(i0 + quarter, t, y1);
+                gstore(i0 + 2 * quarter, t, y2);
+                gstore(i0 + 3 * quarter, t, y3);
+            } else {
+                A::st(tile, a0, y0);
+                A::st(tile, a1, y1);
+                A::st(tile, a2, y2);
+                A::st(tile, a3, y3);
+            }
         }
-        __syncthreads();
+        if (!out_direct) __syncthreads();
+        first = false;
     }
 }
 
@@ -139,33 +161,51 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
 
     for (uint32_t i = tid; i < (M >> 1); i += NTT_THREADS) ntt_st(stw + i, ntt_ld(a.sub_tw + i));
 
-    uint64_t base = 0, c0 = 0, q = 0, k1base = 0;
+    uint64_t base = 0, c0 = 0, q = 0, k1base = 0, obase = 0;
     if (!a.last) {
         const uint64_t tiles_per_row = a.S >> logT;
         const uint64_t row = b / tiles_per_row;
         c0 = (b % tiles_per_row) << logT;
         base = row * a.row_len + c0;
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t t = idx & (T - 1), i = idx >> logT;
-            const uint64_t g = base + (uint64_t)i * a.S + t;
-            Fr x = ntt_ld(a.in + g);
-            if (a.pre_full) x = fe_mul(x, ntt_ld(a.pre_full + g));
-            else if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
-            ntt_st(tile + idx, x);
-        }
     } else {
         q = b % a.Q;
         k1base = (b / a.Q) << logT;
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t i = idx & (M - 1), t = idx >> k;
-            const uint64_t g = ((k1base + t) * a.Q + q) * M + i;
-            Fr x = ntt_ld(a.in + g);
-            if (a.pre_full) x = fe_mul(x, ntt_ld(a.pre_full + g));
-            else if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
-            ntt_st(tile + ((i << logT) + t), x);
+        obase = k1base + a.N1 * ((q / a.N3) + a.N2 * (q % a.N3));
+    }
+    // element (i, t) of this workgroup's tile, pre-factor applied / its place in the output with the closing factor
+    auto gload = [&](uint32_t i, uint32_t t) -> Fr {
+        const uint64_t g = a.last ? ((k1base + t) * a.Q + q) * M + i : base + (uint64_t)i * a.S + t;
+        Fr x = ntt_ld(a.in + g);
+        if (a.pre_full) x = fe_mul(x, ntt_ld(a.pre_full + g));
+        else if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
+        return x;
+    };
+    auto gstore = [&](uint32_t i, uint32_t t, Fr x) {   // the value at in-tile position i is output kk = bitrev_k(i)
+        const uint32_t kk = (k ? (__brev(i) >> (32 - k)) : 0u);
+        if (!a.last) {
+            if (a.tw_full) x = fe_mul(x, ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t)));
+            else x = fe_mul(x, ntt_pow2l(a.tw_lo, a.tw_hi, a.tw_h, (c0 + t) * (uint64_t)kk));
+            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), x);
+        } else {
+            const uint64_t o = obase + t + a.out_stride * kk;
+            if (a.post_full) x = fe_mul(x, ntt_ld(a.post_full + o));
+            else if (a.post_lo) x = fe_mul(x, ntt_pow2l(a.post_lo, a.post_hi, a.post_h, o));
+            if (a.scale) x = fe_mul(x, ntt_ld(a.scale));
+            ntt_st(a.out + o, x);
+        }
+    };
+    const bool direct = a.radix4 == 2 && k >= 2;
+    if (!direct) {
+        if (!a.last) {
+            for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) ntt_st(tile + idx, gload(idx >> logT, idx & (T - 1)));
+        } else {
+            for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+                const uint32_t i = idx & (M - 1), t = idx >> k;
+                ntt_st(tile + ((i << logT) + t), gload(i, t));
+            }
         }
     }
-    __syncthreads();
+    __syncthreads();   // (direct: the sub-transform's twiddles are in LDS)
 
     // k radix-2 DIF stages, natural order in, bit-reversed order out (within the tile).
     // The twiddle of a butterfly is w^(pos << s) with pos < half: it is 1 for pos = 0, i.e. for EVERY butterfly of the
@@ -173,7 +213,8 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     // skipped -- 0.75 of the k/2 multiplications per element of a pass (19 % of a 2^20 transform's).  For half = 2 the
     // butterflies are dealt out so that a whole sweep of the workgroup has the same pos (no divergence inside a wave).
     const uint32_t nb = E >> 1;
-    if (a.radix4) ntt_stages_radix4<NttArith32>(tile, stw, k, logT, E, tid, NTT_THREADS);
+    if (a.radix4) ntt_stages_radix4<NttArith32>(tile, stw, k, logT, E, tid, NTT_THREADS, direct, a.last != 0, gload, gstore);
+    if (direct) return;
     for (uint32_t s = a.radix4 ? k : 0u; s < k; ++s) {
         const uint32_t lh = k - 1 - s;  // log2(half)
         const uint32_t half = 1u << lh;
@@ -205,32 +246,10 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
         __syncthreads();
     }
 
-    if (!a.last) {
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t t = idx & (T - 1), kk = idx >> logT;
-            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
-            Fr x = ntt_ld(tile + ((src << logT) + t));
-            if (a.tw_full) {
-                x = fe_mul(x, ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t)));
-            } else {
-                const uint64_t e = (c0 + t) * (uint64_t)kk;
-                x = fe_mul(x, ntt_pow2l(a.tw_lo, a.tw_hi, a.tw_h, e));
-            }
-            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), x);
-        }
-    } else {
-        const uint64_t qrev = (q / a.N3) + a.N2 * (q % a.N3);
-        const uint64_t obase = k1base + a.N1 * qrev;
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t t = idx & (T - 1), kk = idx >> logT;
-            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
-            Fr x = ntt_ld(tile + ((src << logT) + t));
-            const uint64_t o = obase + t + a.out_stride * kk;
-            if (a.post_full) x = fe_mul(x, ntt_ld(a.post_full + o));
-            else if (a.post_lo) x = fe_mul(x, ntt_pow2l(a.post_lo, a.post_hi, a.post_h, o));
-            if (a.scale) x = fe_mul(x, ntt_ld(a.scale));
-            ntt_st(a.out + o, x);
-        }
+    for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+        const uint32_t t = idx & (T - 1), kk = idx >> logT;
+        const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
+        gstore(src, t, ntt_ld(tile + ((src << logT) + t)));
     }
 }
 
@@ -263,34 +282,52 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
 
     for (uint32_t i = tid; i < (M >> 1); i += NTT_THREADS) lds_st30(stw + 9 * i, fr30_unpack(ntt_ld(a.sub_tw + i)));
 
-    uint64_t base = 0, c0 = 0, q = 0, k1base = 0;
+    uint64_t base = 0, c0 = 0, q = 0, k1base = 0, obase = 0;
     if (!a.last) {
         const uint64_t tiles_per_row = a.S >> logT;
         const uint64_t row = b / tiles_per_row;
         c0 = (b % tiles_per_row) << logT;
         base = row * a.row_len + c0;
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t t = idx & (T - 1), i = idx >> logT;
-            const uint64_t g = base + (uint64_t)i * a.S + t;
-            Fr30 x = fr30_unpack(ntt_ld(a.in + g));
-            if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
-            lds_st30(tile + 9 * idx, x);
-        }
     } else {
         q = b % a.Q;
         k1base = (b / a.Q) << logT;
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t i = idx & (M - 1), t = idx >> k;
-            const uint64_t g = ((k1base + t) * a.Q + q) * M + i;
-            Fr30 x = fr30_unpack(ntt_ld(a.in + g));
-            if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
-            lds_st30(tile + 9 * ((i << logT) + t), x);
+        obase = k1base + a.N1 * ((q / a.N3) + a.N2 * (q % a.N3));
+    }
+    auto gload = [&](uint32_t i, uint32_t t) -> Fr30 {
+        const uint64_t g = a.last ? ((k1base + t) * a.Q + q) * M + i : base + (uint64_t)i * a.S + t;
+        Fr30 x = fr30_unpack(ntt_ld(a.in + g));
+        if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
+        return x;
+    };
+    auto gstore = [&](uint32_t i, uint32_t t, Fr30 x) {   // the value at in-tile position i is output kk = bitrev_k(i)
+        const uint32_t kk = (k ? (__brev(i) >> (32 - k)) : 0u);
+        if (!a.last) {
+            x = fr30_mul(x, fr30_unpack(ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t))));
+            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), fr30_pack(x));  // < 2r: the next pass takes it as it is
+        } else {
+            const uint64_t o = obase + t + a.out_stride * kk;
+            if (a.post_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.post_full + o)));
+            else if (a.scale) x = fr30_mul(x, fr30_unpack(ntt_ld(a.scale)));
+            else x = fr30_mul(x, fr30_const_one());
+            ntt_st(a.out + o, fr30_to_canonical(x));
+        }
+    };
+    const bool direct = a.radix4 == 2 && k >= 2;
+    if (!direct) {
+        if (!a.last) {
+            for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) lds_st30(tile + 9 * idx, gload(idx >> logT, idx & (T - 1)));
+        } else {
+            for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+                const uint32_t i = idx & (M - 1), t = idx >> k;
+                lds_st30(tile + 9 * ((i << logT) + t), gload(i, t));
+            }
         }
     }
     __syncthreads();
 
     const uint32_t nb = E >> 1;
-    if (a.radix4) ntt_stages_radix4<NttArith30>(tile, stw, k, logT, E, tid, NTT_THREADS);
+    if (a.radix4) ntt_stages_radix4<NttArith30>(tile, stw, k, logT, E, tid, NTT_THREADS, direct, a.last != 0, gload, gstore);
+    if (direct) return;
     for (uint32_t s = a.radix4 ? k : 0u; s < k; ++s) {
         const uint32_t lh = k - 1 - s;
         const uint32_t half = 1u << lh;
@@ -321,28 +358,10 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
         }
         __syncthreads();
     }
-
-    if (!a.last) {
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t t = idx & (T - 1), kk = idx >> logT;
-            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
-            Fr30 x = lds_ld30(tile + 9 * ((src << logT) + t));
-            x = fr30_mul(x, fr30_unpack(ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t))));
-            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), fr30_pack(x));  // < 2r: the next pass takes it as it is
-        }
-    } else {
-        const uint64_t qrev = (q / a.N3) + a.N2 * (q % a.N3);
-        const uint64_t obase = k1base + a.N1 * qrev;
-        for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
-            const uint32_t t = idx & (T - 1), kk = idx >> logT;
-            const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
-            Fr30 x = lds_ld30(tile + 9 * ((src << logT) + t));
-            const uint64_t o = obase + t + a.out_stride * kk;
-            if (a.post_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.post_full + o)));
-            else if (a.scale) x = fr30_mul(x, fr30_unpack(ntt_ld(a.scale)));
-            else x = fr30_mul(x, fr30_const_one());
-            ntt_st(a.out + o, fr30_to_canonical(x));
-        }
+    for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
+        const uint32_t t = idx & (T - 1), kk = idx >> logT;
+        const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
+        gstore(src, t, lds_ld30(tile + 9 * ((src << logT) + t)));
     }
 }
 
