@@ -200,6 +200,7 @@ struct typlonk_ctx {
     int ntt_fr30 = 1;              // TYPLONK_NTT_FR30: 0 = off, 1 = 9 x 30-bit butterflies (fr30.hpp) up to 2^19,
                                    // 2 = for every transform (the 4096-element tiles of 2^20 are then not used)
     uint32_t ntt_full_max_log = 24;
+    int ntt_tile_log = 0;          // TYPLONK_NTT_TILE (measurement): tiles of the two-pass 2^20 transform, see ntt_run
     bool ntt_direct = true;        // TYPLONK_NTT_DIRECT=0: the radix-4 groups all go through the LDS tile (staging copy in / out)
     bool ntt_radix4 = true;        // TYPLONK_NTT_RADIX=2: one LDS round trip per butterfly stage (the round-2 form)
     Comm comm;                     // typlonk_comm_init: RCCL communicator of this rank (world = 0: none)
@@ -522,8 +523,13 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     // beside them -- prove() 38.1 -> 38.3 ms in the same-box A/B)
     bool big = ctx->ntt_big_tiles && log_n == 20 && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
     if (big && ctx->ntt_fr30 == 2 && ctx->ntt_full_tables) big = false;  // 36 B per element: 4096 of them do not fit
-    const uint32_t cap = big ? 12 : 10;        // log2 of the tile capacity
-    const unsigned threads = big ? 1024 : 256;
+    // log2 of the tile capacity; TYPLONK_NTT_TILE=11 tries 2048-element tiles (two columns, two workgroups per CU) for the
+    // two-pass 2^20 transform
+    // TYPLONK_NTT_TILE: 12 = 4096-element tiles in both passes, 11 = 2048 in both, 0 (default) = 4096 in the first
+    // (strided: four columns make 128-byte runs) and 2048 in the last (rows are contiguous, and two workgroups per CU
+    // overlap each other's load / compute / store phases: 0.0775 -> 0.070 ms, profiles/r03_ntt_2_20_tiles.txt)
+    const uint32_t cap_first = big ? (ctx->ntt_tile_log == 11 ? 11u : 12u) : 10u;
+    const uint32_t cap_last = big ? (ctx->ntt_tile_log == 12 ? 12u : 11u) : 10u;
     split_log(log_n, ks, &P, big);
     const std::string dir = inverse ? "i" : "f";
 
@@ -653,7 +659,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
                 if (rc) return rc;
             }
             a.tw_full = full.d;
-            logT = std::min<uint32_t>(cap - k, ilog2_u64(a.S));
+            logT = std::min<uint32_t>(cap_first - k, ilog2_u64(a.S));
         } else {
             const uint64_t N1 = 1ull << ks[0];
             a.N1 = (P == 1) ? 1 : N1;
@@ -661,7 +667,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             a.N2 = (P >= 3) ? (1ull << ks[1]) : 1;
             a.N3 = (P == 4) ? (1ull << ks[2]) : 1;
             a.out_stride = N / M;
-            logT = (P == 1) ? 0 : std::min<uint32_t>(cap - k, ks[0]);
+            logT = (P == 1) ? 0 : std::min<uint32_t>(cap_last - k, ks[0]);
             a.post_lo = post_lo.d;
             a.post_hi = post_hi.d;
             a.post_h = post_h;
@@ -700,6 +706,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             a.scale = last ? scale30.d : nullptr;
         }
         const size_t lds = (size_t)(E + std::max<uint64_t>(M / 2, 1)) * (f30 ? 36 : sizeof(Fr));
+        const unsigned threads = big ? (unsigned)std::max<uint64_t>(E / 4, 64) : 256u;
         {
             static const char* names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};
             StageTimer st(ctx, names[p]);
@@ -1365,6 +1372,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_NTT_FULL_MAX_LOG")) ctx->ntt_full_max_log = (uint32_t)atoi(e);
     if (const char* e = getenv("TYPLONK_NTT_RADIX")) ctx->ntt_radix4 = atoi(e) != 2;
     if (const char* e = getenv("TYPLONK_NTT_DIRECT")) ctx->ntt_direct = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_NTT_TILE")) ctx->ntt_tile_log = atoi(e);
     *out = ctx;
     return TYPLONK_OK;
 }
