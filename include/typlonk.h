@@ -110,7 +110,10 @@ int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
  *                            typlonk_msm_g1_devptr / _batch_devptr on an SRS shard + the fold: every rank passes the
  *                            full coefficient vector(s) and gets the full sum(s) (collective).
  * typlonk_prove on a context with a communicator and an SRS shard folds the commitments of every round itself, so
- * all ranks hash identical points, squeeze identical challenges and return the identical proof. */
+ * all ranks hash identical points, squeeze identical challenges and return the identical proof.
+ * Failure on one rank: the *_sharded_* entry points and typlonk_prove still join the collective of the step that
+ * failed, with flagged records, so that rank returns its own error code and every other rank TYPLONK_ERR_COMM
+ * (typlonk_last_error names the rank) -- nobody is left waiting; the communicator stays usable. */
 #define TYPLONK_COMM_ID_BYTES 128
 int typlonk_comm_unique_id(uint8_t id[TYPLONK_COMM_ID_BYTES]);
 int typlonk_comm_init(typlonk_ctx* ctx, const uint8_t id[TYPLONK_COMM_ID_BYTES], int rank, int world);

@@ -82,6 +82,10 @@ int main() {
     OK(typlonk_msm_g1_batch_devptr(ctx, shard, ptrs, ms, 3, bx, bxi));
     OK(typlonk_msm_g1_sharded_batch_devptr(ctx, shard, ptrs, ms, 3, by, byi));
     REQUIRE(std::memcmp(bx, by, sizeof(bx)) == 0 && std::memcmp(bxi, byi, 3) == 0 && byi[2] == 1);
+    // a local failure travels with the collective instead of leaving the peers inside it
+    REQUIRE(typlonk_msm_g1_sharded_devptr(ctx, shard, typlonk_buf_devptr(buf), n + 1, b, &bi) == TYPLONK_ERR_LENGTH);
+    OK(typlonk_msm_g1_sharded_devptr(ctx, shard, typlonk_buf_devptr(buf), n, b, &bi));
+    REQUIRE(ai == bi && std::memcmp(a, b, sizeof(a)) == 0);
     OK(typlonk_buf_free(ctx, buf));
     OK(typlonk_comm_destroy(ctx));
     OK(typlonk_comm_info(ctx, &rank, &world));

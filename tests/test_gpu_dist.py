@@ -126,6 +126,14 @@ def test_native_rccl_exchange_behind_the_c_abi(built):
         for (x, i), (y, j) in zip(res, ref):
             assert (x == y).all() and i == j
         assert res[2][1] == 1                                         # the empty sum is the identity, also after the fold
+        # a rank whose local MSM fails still joins the collective (flagged records) and reports ITS error; the
+        # communicator stays usable
+        from typlonk_amd.capi import ERR_LENGTH
+        with pytest.raises(TyplonkError) as e:
+            ctx.msm_sharded_devptr(shard, buf.devptr, n + 100)        # m > total length: kzg/src/lib.rs:43
+        assert e.value.code == ERR_LENGTH
+        again = ctx.msm_sharded_devptr(shard, buf.devptr, n)
+        assert (again[0] == b[0]).all() and again[1] == b[1]
         pts = [a, loc, (np.zeros(12, dtype=np.uint64), 1)] * 7        # 21 points: more than the first reservation
         back = ctx.comm_fold(pts)
         for (x, i), (y, j) in zip(pts, back):

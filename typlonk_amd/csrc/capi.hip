@@ -1217,23 +1217,41 @@ int comm_reserve(typlonk_ctx* ctx, size_t count) {
 
 // every point <- sum over the ranks of that rank's point: all-gather of the records on the context's stream, fold in
 // rank order on the host (fixed order and a canonical result: bit-identical on every rank)
-int comm_fold(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count) {
+//
+// local_rc: the status of the local work the points come from.  A rank whose MSM or prover round failed must not leave
+// its peers waiting inside the collective, so it still takes part -- with its records flagged (bits 32.. of the flag
+// word) -- and EVERY rank then returns an error: the failing rank its own code, the others TYPLONK_ERR_COMM naming it.
+int comm_fold(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count, int local_rc = TYPLONK_OK) {
     Comm& c = ctx->comm;
     if (!c.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
-    if (!count) return TYPLONK_OK;
+    if (!count) return local_rc;
+    const std::string local_err = local_rc ? ctx->err : std::string();
     int rc = comm_reserve(ctx, count);
     if (rc) return rc;
     uint64_t* out = c.h_buf;
     uint64_t* back = c.h_buf + c.cap * COMM_REC;
     for (size_t i = 0; i < count; ++i) {
-        memcpy(out + i * COMM_REC, xy + 12 * i, 96);
-        out[i * COMM_REC + 12] = inf[i];
+        if (local_rc) {
+            memset(out + i * COMM_REC, 0, 96);
+            out[i * COMM_REC + 12] = 1u | ((uint64_t)(uint32_t)(-local_rc) << 32);   // identity + the error code
+        } else {
+            memcpy(out + i * COMM_REC, xy + 12 * i, 96);
+            out[i * COMM_REC + 12] = inf[i];
+        }
     }
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemcpyAsync(c.d_send, out, count * COMM_REC * 8, hipMemcpyHostToDevice, s));
     NCCLCHK(rccl_api()->AllGather(c.d_send, c.d_recv, count * COMM_REC, ncclUint64, c.comm, s));
     HIPCHK(hipMemcpyAsync(back, c.d_recv, (size_t)c.world * count * COMM_REC * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    for (int r = 0; r < c.world; ++r) {
+        const uint64_t flag = back[(size_t)r * count * COMM_REC + 12];
+        if (flag >> 32) {
+            if (local_rc) return fail(ctx, local_rc, local_err);
+            return fail(ctx, TYPLONK_ERR_COMM, "rank " + std::to_string(r) + " failed before the exchange (its error code " +
+                                                   std::to_string(-(int)(flag >> 32)) + ")");
+        }
+    }
     std::vector<uint64_t> pxy((size_t)c.world * 12);
     std::vector<uint8_t> pinf((size_t)c.world);
     for (size_t i = 0; i < count; ++i) {
@@ -1584,9 +1602,9 @@ int typlonk_msm_g1_sharded_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void*
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     if (!ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
     HIPCHK(hipSetDevice(ctx->device));
-    int rc = msm_run(ctx, srs_id, (const Fr*)d_scalars, m, out_xy, out_inf);
-    if (rc) return rc;
-    return comm_fold(ctx, out_xy, out_inf, 1);
+    if (!out_xy || !out_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
+    const int rc = msm_run(ctx, srs_id, (const Fr*)d_scalars, m, out_xy, out_inf);
+    return comm_fold(ctx, out_xy, out_inf, 1, rc);   // a failed rank still joins the collective, flagged
 }
 
 int typlonk_msm_g1_sharded_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m,
@@ -1594,9 +1612,9 @@ int typlonk_msm_g1_sharded_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     if (!ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
     HIPCHK(hipSetDevice(ctx->device));
-    int rc = msm_batch(ctx, srs_id, d_scalars, m, count, out_xy, out_inf);
-    if (rc) return rc;
-    return comm_fold(ctx, out_xy, out_inf, count);   // one collective for the whole group
+    if (!out_xy || !out_inf || !m) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    const int rc = msm_batch(ctx, srs_id, d_scalars, m, count, out_xy, out_inf);
+    return comm_fold(ctx, out_xy, out_inf, count, rc);   // one collective for the whole group; failures travel with it
 }
 
 int typlonk_msm_g1_dev(typlonk_ctx* ctx, uint32_t srs_id, const typlonk_buf* scalars, size_t offset, size_t m,
@@ -2362,15 +2380,15 @@ int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const 
                   const typlonk_buf* pi_evals, const uint64_t cosets[3][4], typlonk_proof* out) {
     if (!ctx || !wire_evals || !cosets || !out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
     typlonk_prover* p = nullptr;
-    int rc = typlonk_prover_round1(ctx, srs_id, circuit_id, wire_evals, pi_evals, &p, out->commit_xy, out->commit_inf);
-    if (rc) return rc;
     // An SRS shard on a context with a communicator: every round's partial commitments are folded over the ranks (one
-    // all-gather per round), so all ranks hash the same points and end with the same proof.  A failure on one rank
-    // only (an OOM, say) leaves its peers in the collective -- as any collective program -- so errors that every
-    // rank sees alike (unsatisfied witness, bad arguments) are the ones reported cleanly.
+    // all-gather per round), so all ranks hash the same points and end with the same proof.  A rank whose round fails
+    // (an OOM, say) still joins that round's collective with flagged records, so its peers return TYPLONK_ERR_COMM
+    // instead of waiting for ever (comm_fold).
     const bool folds = comm_folds(ctx, srs_id);
-    if (folds && (rc = comm_fold(ctx, &out->commit_xy[0][0], out->commit_inf, 3))) {
-        typlonk_prover_free(p);
+    int rc = typlonk_prover_round1(ctx, srs_id, circuit_id, wire_evals, pi_evals, &p, out->commit_xy, out->commit_inf);
+    if (folds) rc = comm_fold(ctx, &out->commit_xy[0][0], out->commit_inf, 3, rc);
+    if (rc) {
+        if (p) typlonk_prover_free(p);
         return rc;
     }
     // (beta, gamma) <- H([a], [b], [c])                                                   proof.rs:111
@@ -2381,7 +2399,7 @@ int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const 
     memcpy(out->beta, ch, 32);
     memcpy(out->gamma, ch + 4, 32);
     rc = typlonk_prover_round2(p, out->beta, out->gamma, cosets, out->z_xy, &out->z_inf);
-    if (!rc && folds) rc = comm_fold(ctx, out->z_xy, &out->z_inf, 1);
+    if (folds) rc = comm_fold(ctx, out->z_xy, &out->z_inf, 1, rc);
     if (!rc) {
         // (alpha, zeta) <- H([a], [b], [c], [Z])                                          proof.rs:133-136
         g.digest(out->z_xy, out->z_inf);
@@ -2389,19 +2407,21 @@ int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const 
         memcpy(out->alpha, ch, 32);
         memcpy(out->zeta, ch + 4, 32);
         rc = typlonk_prover_round3(p, out->alpha, out->zeta, &out->tail);
-        if (folds && (rc == TYPLONK_OK || rc == TYPLONK_ERR_UNSATISFIED)) {   // r(zeta) is the same on every rank
+        if (folds) {   // (an unsatisfied witness, r(zeta) != 0, is the same on every rank: the points are still folded)
+            const int round_rc = rc;
             uint64_t xy[9][12];
             uint8_t inf[9];
             memcpy(xy, out->tail.t_xy, 3 * 96);
             memcpy(xy + 3, out->tail.w_xy, 6 * 96);
             memcpy(inf, out->tail.t_inf, 3);
             memcpy(inf + 3, out->tail.w_inf, 6);
-            const int r2 = comm_fold(ctx, &xy[0][0], inf, 9);
+            const int r2 = comm_fold(ctx, &xy[0][0], inf, 9, round_rc == TYPLONK_ERR_UNSATISFIED ? TYPLONK_OK : round_rc);
             memcpy(out->tail.t_xy, xy, 3 * 96);
             memcpy(out->tail.w_xy, xy + 3, 6 * 96);
             memcpy(out->tail.t_inf, inf, 3);
             memcpy(out->tail.w_inf, inf + 3, 6);
             if (r2) rc = r2;
+            else rc = round_rc;
         }
     }
     typlonk_prover_free(p);
