@@ -209,10 +209,25 @@ __global__ __launch_bounds__(RC2_THREADS) void msm_rc2_planes_kernel(const uint3
     const uint32_t litems = kind ? sh.cl : sh.ch, lp = kind ? lpc : lpr;
     const uint32_t* src = kind ? pcol : prow;
     const uint32_t np = 1u << (litems + lp);
+    const uint64_t sbase = (uint64_t)set << (litems + lp);
     G1Xyzz v = G1Xyzz::inf();
-    for (uint32_t idx = threadIdx.x; idx < np; idx += blockDim.x) {
-        const uint32_t item = idx >> lp;
-        if ((rc_weight(sh, set, kind, item) >> bit) & 1u) v = g1_add(v, ld_xyzz(src, ((uint64_t)set << (litems + lp)) + idx));
+    if (rc_set_v(sh, set) == 0) {
+        // Only the items whose weight has the bit: rows weigh `item`, columns `item + 1` (launch.hpp), so the j-th selected
+        // weight is j with a 1 inserted at position `bit` (columns: the single weight 2^cl for bit = cl).  Half the
+        // partials, so that 2^16 buckets need one sweep of the workgroup instead of two (one dependent addition less).
+        const bool top = kind && bit == sh.cl;
+        const uint32_t nsel = (top ? 1u : (1u << (litems - 1))) << lp;
+        for (uint32_t idx = threadIdx.x; idx < nsel; idx += blockDim.x) {
+            const uint32_t j = idx >> lp, part = idx & ((1u << lp) - 1);
+            const uint32_t w = top ? (1u << sh.cl) : (((j >> bit) << (bit + 1)) | (1u << bit) | (j & ((1u << bit) - 1)));
+            const uint32_t item = w - kind;
+            v = g1_add(v, ld_xyzz(src, sbase + ((uint64_t)item << lp) + part));
+        }
+    } else {
+        for (uint32_t idx = threadIdx.x; idx < np; idx += blockDim.x) {
+            const uint32_t item = idx >> lp;
+            if ((rc_weight(sh, set, kind, item) >> bit) & 1u) v = g1_add(v, ld_xyzz(src, sbase + idx));
+        }
     }
 #pragma unroll 1
     for (int mask = 1; mask < 64; mask <<= 1) v = butterfly_add(v, mask);
@@ -255,7 +270,9 @@ void launch_msm_rc2_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t*
     hipLaunchKernelGGL(msm_rc2_sums_kernel, dim3((nwave_row + nwave_col + 3) / 4), dim3(256), 0, s, buckets, sh, sr, sc, nwave_row,
                        nwave_row + nwave_col, prow, pcol);
     const uint32_t lpr = sh.cl - 6 - sr, lpc = sh.ch - 6 - sc;
-    const uint32_t np = 1u << ((sh.ch + lpr) > (sh.cl + lpc) ? (sh.ch + lpr) : (sh.cl + lpc));
+    // partials one (kind, bit) sums: half of the items' (the ones whose weight has the bit) unless a set has virtual copies
+    uint32_t np = 1u << ((sh.ch + lpr) > (sh.cl + lpc) ? (sh.ch + lpr) : (sh.cl + lpc));
+    if (sh.top_v == 0 && np > 64) np >>= 1;
     const uint32_t threads = np < 64 ? 64u : (np > (uint32_t)RC2_THREADS ? (uint32_t)RC2_THREADS : np);
     hipLaunchKernelGGL(msm_rc2_planes_kernel, dim3(sh.nsets * 2 * RC_NB), dim3(threads), 0, s, prow, pcol, sh, lpr, lpc, out);
 }
