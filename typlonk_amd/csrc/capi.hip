@@ -189,6 +189,7 @@ struct typlonk_ctx {
     int msm_chunks = 0;            // TYPLONK_MSM_CHUNKS: chunks of a stand-alone MSM (0 = choose by length)
     bool msm_side_prio = false;    // TYPLONK_MSM_SIDE_PRIO=1: the side stream of the chunk sorts at the highest stream priority
                                    // (measured: no effect -- 2.61-2.65 ms either way, profiles/r03_side_prio.txt)
+    bool msm_host_planes = true;   // TYPLONK_MSM_HOST_PLANES=0: bit planes go to device memory and are copied to the host
     bool msm_stagger = true;       // TYPLONK_MSM_STAGGER=0: the second chunk's sort runs beside the first one's (round-2 order)
     bool msm_lanes_split = true;   // TYPLONK_MSM_LANES_SPLIT=0: one lane count for every bucket
     int msm_lanes = 0;             // TYPLONK_MSM_LANES: lanes per bucket of the accumulation (0 = choose by bucket load)
@@ -998,14 +999,17 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if ((rc = ensure(ctx, ws.rc_sums, (((uint64_t)nsets << sh.ch) + ((uint64_t)nsets << sh.cl)) * 192))) return rc;
         if ((rc = ensure(ctx, ws.rc_bits, (uint64_t)nsets * 2 * RC_NB * 64 * 192))) return rc;
         if ((rc = ensure(ctx, ws.rc_out, (uint64_t)nsets * 2 * RC_NB * 192))) return rc;
+        // one shared bucket set (table mode): the last kernel of the reduction writes its <= 32 plane points straight into
+        // the pinned host landing zone (device-visible) -- no copy kernel between it and the host's wait
+        uint32_t* planes_out = (nsets == 1 && ctx->msm_host_planes) ? ws.host_wins : (uint32_t*)ws.rc_out.p;
         StageTimer st(ctx, "msm_reduce", s);
         // two launches for small bucket sets, where the reduction is a latency chain; big sets are work-bound and the
         // four-launch form wastes fewer lanes (2^19 buckets: 0.39 ms against 0.49, profiles/r03_shard_variants.jsonl)
         if (!ctx->msm_rc4 && msm_rc2_ok(sh) && (ctx->msm_rc2_force || nb <= (1u << 17)))
-            launch_msm_rc2_reduce(buckets, sh, (uint32_t*)ws.part_b.p, (uint32_t*)ws.part_a.p, (uint32_t*)ws.rc_out.p, s);
+            launch_msm_rc2_reduce(buckets, sh, (uint32_t*)ws.part_b.p, (uint32_t*)ws.part_a.p, planes_out, s);
         else
             launch_msm_rc_reduce(buckets, sh, (uint32_t*)ws.part_b.p, (uint32_t*)ws.part_a.p, (uint32_t*)ws.rc_sums.p,
-                                 (uint32_t*)ws.rc_bits.p, (uint32_t*)ws.rc_out.p, s);
+                                 (uint32_t*)ws.rc_bits.p, planes_out, s);
         if (nsets > 1) {
             // plain MSM: per-set powers of two on the device, the host keeps its Horner over the windows
             uint32_t* set_sums = (uint32_t*)ws.part_a.p;  // the column partials are consumed by now
@@ -1015,7 +1019,8 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             ws.rc = false;
         } else {
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(ws.host_wins, ws.rc_out.p, (size_t)nsets * 2 * RC_NB * 192, hipMemcpyDeviceToHost, s));
+            if (planes_out != ws.host_wins)
+                HIPCHK(hipMemcpyAsync(ws.host_wins, ws.rc_out.p, (size_t)nsets * 2 * RC_NB * 192, hipMemcpyDeviceToHost, s));
         }
     } else {
         StageTimer st(ctx, "msm_reduce", s);
@@ -1375,6 +1380,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         ctx->msm_rc2_force = (strcmp(e, "rc2") == 0);
     }
     if (const char* e = getenv("TYPLONK_MSM_STAGGER")) ctx->msm_stagger = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_MSM_HOST_PLANES")) ctx->msm_host_planes = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_SIDE_PRIO")) ctx->msm_side_prio = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES_SPLIT")) ctx->msm_lanes_split = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
