@@ -1,4 +1,7 @@
 // MSM bucket reduction: per-window sum_k k*B_k with running sums + wavefront __shfl_xor butterflies.
+#include <stdlib.h>
+#include <string.h>
+
 #include "launch.hpp"
 #include "msm_common.hpp"
 
@@ -321,6 +324,16 @@ void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* 
     const FoldSeg a = seg(pb, rsum, nrow, sh.cl - sh.llc), b = seg(pa, csum, ncol, sh.ch - sh.lhc);
     const uint32_t ba = (a.threads + 63) / 64, bb = (b.threads + 63) / 64;
     hipLaunchKernelGGL(msm_fold_seq_kernel, dim3(ba + bb), dim3(64), 0, s, a, b, ba);
+    static const bool bits_final = [] { const char* e = getenv("TYPLONK_MSM_PLANES"); return e && strcmp(e, "split") == 0; }();
+    if (!bits_final && sh.ch >= 6 && sh.cl >= 6) {
+        // the bit planes of the R + C sums in ONE launch (msm_rc2_planes_kernel with one "partial" per row / column):
+        // a workgroup per (set, kind, bit) butterfly-sums the selected sums per wavefront and across wavefronts
+        uint32_t np = 1u << (sh.ch > sh.cl ? sh.ch : sh.cl);
+        if (sh.top_v == 0 && np > 64) np >>= 1;
+        const uint32_t threads = np < 64 ? 64u : (np > (uint32_t)RC2_THREADS ? (uint32_t)RC2_THREADS : np);
+        hipLaunchKernelGGL(msm_rc2_planes_kernel, dim3(sh.nsets * 2 * RC_NB), dim3(threads), 0, s, rsum, csum, sh, 0u, 0u, out);
+        return;
+    }
     const uint32_t rw = ((1u << sh.ch) + 63) / 64, cw = ((1u << sh.cl) + 63) / 64;
     const uint32_t wps = (sh.ch + 1) * rw + (sh.cl + 1) * cw;
     hipLaunchKernelGGL(msm_rc_bits_kernel, dim3(sh.nsets * wps), dim3(64), 0, s, sums, sh, rw, cw, bitsum);
