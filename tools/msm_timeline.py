@@ -8,9 +8,9 @@ from collections import defaultdict
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("ty::", "").split("<")[0])
               for r in csv.DictReader(open(sys.argv[1])))
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-# an MSM ends with the device-to-host copy of its bit planes / window sums
-last = "__amd_rocclr_copyBuffer"
-ends = [i for i, r in enumerate(rows) if r[2] == last]
+# an MSM ends with the kernel that writes its bit planes to the host, or with the device-to-host copy of its window sums
+ends = [i for i, r in enumerate(rows)
+        if r[2] in ("__amd_rocclr_copyBuffer", "msm_rc2_planes_kernel") and (i + 1 == len(rows) or rows[i + 1][2] != "__amd_rocclr_copyBuffer")]
 starts = [e + 1 for e in ends][-(reps + 1):]
 seqs = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
 shape = tuple(r[2] for r in seqs[-1])
