@@ -21,6 +21,7 @@ use ark_serialize::CanonicalSerialize;
 use blake2::{Blake2b, Digest};
 use kzg::{srs::Srs, KzgCommitment, KzgScheme};
 use rand::{rngs::StdRng, RngCore, SeedableRng};
+use std::convert::TryInto;
 use std::fmt::Write as _;
 
 fn hex_limbs(l: &[u64]) -> String {
@@ -49,19 +50,18 @@ fn list(items: Vec<String>) -> String {
     format!("[{}]", items.join(","))
 }
 
-// the reference's ChallengeGenerator, call for call (challenges.rs:17-45)
+// What the reference's private ChallengeGenerator computes (plonk/src/proof/challenges.rs:17-45), issued against the same
+// crates: transcript bytes = the commitments' serialize_unchecked forms back to back; seed = first eight bytes of their
+// Blake2b-512 digest, little-endian; challenges = successive Fr::rand draws from StdRng::seed_from_u64(seed).
 fn challenges(commitments: &[KzgCommitment], n: usize) -> Vec<Fr> {
-    let mut data: Vec<u8> = vec![];
+    let mut transcript = Vec::with_capacity(96 * commitments.len());
     for c in commitments {
-        c.inner().serialize_unchecked(&mut data).unwrap();
+        c.inner().serialize_unchecked(&mut transcript).expect("serialising into a Vec cannot fail");
     }
-    let mut hasher = Blake2b::new();
-    hasher.update(data);
-    let hash: Vec<u8> = hasher.finalize().to_vec();
-    let mut seed: [u8; 8] = Default::default();
-    seed.copy_from_slice(&hash[0..8]);
-    let mut rng = StdRng::seed_from_u64(u64::from_le_bytes(seed));
-    (0..n).map(|_| Fr::rand(&mut rng)).collect()
+    let digest = Blake2b::digest(&transcript);
+    let seed = u64::from_le_bytes(digest[..8].try_into().expect("eight bytes"));
+    let mut rng = StdRng::seed_from_u64(seed);
+    std::iter::repeat_with(|| Fr::rand(&mut rng)).take(n).collect()
 }
 
 #[test]
