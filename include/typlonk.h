@@ -295,6 +295,14 @@ void* typlonk_buf_devptr(const typlonk_buf* buf);
 /* Fold `count` affine points in index order: the deterministic combine step after an all-gather of
  * per-GPU partial MSM results (RCCL has no elliptic-curve reduction). */
 int typlonk_g1_sum_host(const uint64_t* xy, const uint8_t* inf, size_t count, uint64_t out_xy[12], uint8_t* out_inf);
+/* The fold the library applies after its all-gather, exposed for hosts that run their own exchange (MPI, sockets):
+ * `records` = what an all-gather of the ranks' send buffers yields, rank-major: world x count records of 13 uint64
+ * (12 limbs x || y, then the infinity flag in bits 0..31; bits 32.. non-zero = "this rank failed", its error code).
+ * out point i = sum over ranks r of record (r, i), folded in rank order.  Returns TYPLONK_ERR_COMM and the failing
+ * rank in *failed_rank (may be NULL) when a record is flagged.  Host-only, no GPU. */
+#define TYPLONK_COMM_RECORD_WORDS 13
+int typlonk_g1_fold_records_host(const uint64_t* records, size_t world, size_t count, uint64_t* out_xy /* count*12 */,
+                                 uint8_t* out_inf /* count */, int* failed_rank);
 
 /* ---- measurement -------------------------------------------------------------------------------
  * With profiling on, every kernel stage of the next MSM / NTT call is bracketed by HIP events on

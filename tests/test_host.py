@@ -208,6 +208,34 @@ def test_g1_sum_host_fold(built):
     assert g1_unpack_one(out, oi) == O.g1_mul(O.G1, 6)   # P + P goes through the doubling branch
 
 
+def test_fold_of_all_gathered_records_for_three_ranks(built):
+    """typlonk_g1_fold_records_host -- what the library runs on the output of its ncclAllGather (and what a host with its
+    own exchange can call): records are rank-major, `count` per rank, 12 limbs + flag word.  Three ranks x four points,
+    identities and cancelling points included; a flagged record (bits 32.. of the flag word = a rank's error code) makes
+    the fold fail with TYPLONK_ERR_COMM and name the rank.  The multi-rank index arithmetic cannot run under RCCL on a
+    one-GPU box (one rank per device), so it is pinned here."""
+    from typlonk_amd.capi import ERR_COMM, TyplonkError, g1_fold_records_host
+
+    ks = [[3, 0, 10, 1], [5, 0, O.R - 10, 2], [7, 9, 0, O.R - 3]]     # rank r, point i -> k * G (0 = identity)
+    world, count = 3, 4
+    rec = np.zeros((world, count, 13), dtype=np.uint64)
+    for r in range(world):
+        for i in range(count):
+            limbs, f = O.g1_to_limbs(O.g1_mul(O.G1, ks[r][i]) if ks[r][i] else None)
+            rec[r, i, :12] = limbs
+            rec[r, i, 12] = f
+    got = g1_fold_records_host(rec, world, count)
+    want = [sum(ks[r][i] for r in range(world)) % O.R for i in range(count)]
+    for (xy, inf), k in zip(got, want):
+        assert g1_unpack_one(xy, inf) == (O.g1_mul(O.G1, k) if k else None)
+    assert got[2][1] == 1 and got[3][1] == 1                           # 10 - 10 + 0 and 1 + 2 - 3: the identity
+    bad = rec.copy()
+    bad[1, 2, 12] = np.uint64(1) | (np.uint64(6) << np.uint64(32))     # rank 1 reports error code -6
+    with pytest.raises(TyplonkError) as e:
+        g1_fold_records_host(bad, world, count)
+    assert e.value.code == ERR_COMM and "rank 1" in str(e.value)
+
+
 def test_product_never_imports_oracle():
     """the oracle is test infrastructure: nothing under typlonk_amd/ or include/ may import, link or
     load it"""

@@ -29,7 +29,7 @@ SYMBOLS = [
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
     "typlonk_comm_unique_id", "typlonk_comm_init", "typlonk_comm_destroy", "typlonk_comm_info", "typlonk_comm_fold_g1",
-    "typlonk_msm_g1_sharded_devptr", "typlonk_msm_g1_sharded_batch_devptr",
+    "typlonk_msm_g1_sharded_devptr", "typlonk_msm_g1_sharded_batch_devptr", "typlonk_g1_fold_records_host",
 ]
 
 
@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.typlonk_msm_g1_dev.argtypes = [vp, C.c_uint32, vp, C.c_size_t, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_devptr.argtypes = [vp, C.c_uint32, vp, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_batch_devptr.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, u64p, u8p]
+    lib.typlonk_g1_fold_records_host.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p, u8p, C.POINTER(C.c_int)]
     lib.typlonk_comm_unique_id.argtypes = [u8p]
     lib.typlonk_comm_init.argtypes = [vp, u8p, C.c_int, C.c_int]
     lib.typlonk_comm_destroy.argtypes = [vp]
@@ -179,6 +180,20 @@ def comm_unique_id() -> bytes:
     if rc:
         raise TyplonkError(rc, lib.typlonk_strerror(rc).decode())
     return bytes(buf)
+
+
+def g1_fold_records_host(records, world: int, count: int):
+    """typlonk_g1_fold_records_host: the library's post-all-gather fold on (world, count, 13) uint64 records; returns
+    [(xy[12], inf)] * count, raises TyplonkError(ERR_COMM) naming the rank whose records are flagged.  No GPU needed."""
+    lib = load_library()
+    rec = np.ascontiguousarray(records, dtype=np.uint64).reshape(world, count, 13)
+    out = np.zeros((max(count, 1), 12), dtype=np.uint64)
+    oinf = np.zeros(max(count, 1), dtype=np.uint8)
+    failed = C.c_int(-1)
+    rc = lib.typlonk_g1_fold_records_host(_u64p(rec), world, count, _u64p(out), _u8p(oinf), C.byref(failed))
+    if rc:
+        raise TyplonkError(rc, f"{lib.typlonk_strerror(rc).decode()} (rank {failed.value})")
+    return [(out[i].copy(), int(oinf[i])) for i in range(count)]
 
 
 def g1_sum_host(xy, inf=None):

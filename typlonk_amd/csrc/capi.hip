@@ -1249,25 +1249,15 @@ int comm_fold(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count, int lo
     NCCLCHK(rccl_api()->AllGather(c.d_send, c.d_recv, count * COMM_REC, ncclUint64, c.comm, s));
     HIPCHK(hipMemcpyAsync(back, c.d_recv, (size_t)c.world * count * COMM_REC * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    for (int r = 0; r < c.world; ++r) {
-        const uint64_t flag = back[(size_t)r * count * COMM_REC + 12];
-        if (flag >> 32) {
-            if (local_rc) return fail(ctx, local_rc, local_err);
-            return fail(ctx, TYPLONK_ERR_COMM, "rank " + std::to_string(r) + " failed before the exchange (its error code " +
-                                                   std::to_string(-(int)(flag >> 32)) + ")");
-        }
+    if (local_rc) return fail(ctx, local_rc, local_err);   // (its flagged records made every peer fail too)
+    int failed = -1;
+    rc = typlonk_g1_fold_records_host(back, (size_t)c.world, count, xy, inf, &failed);
+    if (rc == TYPLONK_ERR_COMM) {
+        const uint64_t flag = back[(size_t)failed * count * COMM_REC + 12];
+        return fail(ctx, rc, "rank " + std::to_string(failed) + " failed before the exchange (its error code " +
+                                 std::to_string(-(int)(flag >> 32)) + ")");
     }
-    std::vector<uint64_t> pxy((size_t)c.world * 12);
-    std::vector<uint8_t> pinf((size_t)c.world);
-    for (size_t i = 0; i < count; ++i) {
-        for (int r = 0; r < c.world; ++r) {
-            const uint64_t* rec = back + ((size_t)r * count + i) * COMM_REC;
-            memcpy(&pxy[(size_t)r * 12], rec, 96);
-            pinf[(size_t)r] = (uint8_t)rec[12];
-        }
-        rc = typlonk_g1_sum_host(pxy.data(), pinf.data(), (size_t)c.world, xy + 12 * i, inf + i);
-        if (rc) return fail(ctx, rc, "fold of the gathered partial sums failed");
-    }
+    if (rc) return fail(ctx, rc, "fold of the gathered partial sums failed");
     return TYPLONK_OK;
 }
 
@@ -2510,6 +2500,30 @@ int typlonk_g1_sum_host(const uint64_t* xy, const uint8_t* inf, size_t count, ui
     }
     if (H::xyzz_to_affine(acc, out_xy)) *out_inf = 0;
     else write_affine_out(G1Affine::inf(), out_xy, out_inf);
+    return TYPLONK_OK;
+}
+
+int typlonk_g1_fold_records_host(const uint64_t* records, size_t world, size_t count, uint64_t* out_xy, uint8_t* out_inf,
+                                 int* failed_rank) {
+    static_assert(COMM_REC == TYPLONK_COMM_RECORD_WORDS, "record layout");
+    if (!records || !world || ((!out_xy || !out_inf) && count)) return TYPLONK_ERR_INVALID_ARG;
+    for (size_t r = 0; r < world; ++r)
+        for (size_t i = 0; i < count; ++i)
+            if (records[(r * count + i) * COMM_REC + 12] >> 32) {
+                if (failed_rank) *failed_rank = (int)r;
+                return TYPLONK_ERR_COMM;
+            }
+    std::vector<uint64_t> pxy(world * 12);
+    std::vector<uint8_t> pinf(world);
+    for (size_t i = 0; i < count; ++i) {
+        for (size_t r = 0; r < world; ++r) {   // all-gather layout: rank-major, `count` records per rank
+            const uint64_t* rec = records + (r * count + i) * COMM_REC;
+            memcpy(&pxy[r * 12], rec, 96);
+            pinf[r] = (uint8_t)(rec[12] & 1u);
+        }
+        const int rc = typlonk_g1_sum_host(pxy.data(), pinf.data(), world, out_xy + 12 * i, out_inf + i);
+        if (rc) return rc;
+    }
     return TYPLONK_OK;
 }
 
