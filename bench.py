@@ -505,7 +505,7 @@ def bench_cpu(args, ctx, sh, full, n, log_n, secret, out_xy, out_inf, result) ->
         "terms_per_s": ms / tc, "seconds": tc, "host_cpus": os.cpu_count()}
     # F1 "fair CPU" (SURVEY 8d-ii): bucket method on all host cores (oracle_msm_pippenger) on the FULL vector
     xyf, inff = ctx.srs_download(sh.sid, 0, n)
-    cf = max(4, min(16, n.bit_length() - 4))
+    cf = max(8, min(13, log_n - 5))   # swept on the 2 x 64-core host (tools/cpu_msm_sweep.py): buckets that fit the L2 win
     CO.msm_pippenger(sc_all[:1024], xyf[:1024], inff[:1024], c=8)      # spin the OpenMP team up
     t1 = time.perf_counter()
     f_xy, f_inf, f_ops, f_thr = CO.msm_pippenger(sc_all, xyf, inff, c=cf)

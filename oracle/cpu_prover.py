@@ -78,7 +78,7 @@ def prove(log_n: int, inputs: dict, srs_xy, srs_inf, challenges, threads: int = 
 
     def commit(coeffs, m):
         xy, inf, _, thr = CO.msm_pippenger(coeffs[:m], srs_xy[:m], None if srs_inf is None else srs_inf[:m],
-                                           c=max(4, min(16, log_n - 4)))
+                                           c=max(8, min(13, log_n - 5)))   # tools/cpu_msm_sweep.py
         nthreads[0] = max(nthreads[0], thr)
         return xy, inf
 
