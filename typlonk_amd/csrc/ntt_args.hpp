@@ -15,6 +15,7 @@ struct NttPassArgs {
     uint64_t row_len;  // M * S
     // last pass addressing: row rho = k_1 * Q + q ; out = k_1 + N1 * qrev(q) + out_stride * k_P
     uint64_t N1, Q, N2, N3, out_stride;
+    uint64_t n_valid;  // input elements at index >= n_valid are taken as zero and not read (zero-padded transforms); ~0: all
     const Fr* sub_tw;  // w_M^e, e < M/2
     const Fr* tw_lo;   // w_{row_len}^e,          e < 2^tw_h
     const Fr* tw_hi;   // w_{row_len}^(e * 2^tw_h)

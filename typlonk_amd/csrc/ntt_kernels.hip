@@ -175,6 +175,7 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     // element (i, t) of this workgroup's tile, pre-factor applied / its place in the output with the closing factor
     auto gload = [&](uint32_t i, uint32_t t) -> Fr {
         const uint64_t g = a.last ? ((k1base + t) * a.Q + q) * M + i : base + (uint64_t)i * a.S + t;
+        if (g >= a.n_valid) return Fr::zero();
         Fr x = ntt_ld(a.in + g);
         if (a.pre_full) x = fe_mul(x, ntt_ld(a.pre_full + g));
         else if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     }
     auto gload = [&](uint32_t i, uint32_t t) -> Fr30 {
         const uint64_t g = a.last ? ((k1base + t) * a.Q + q) * M + i : base + (uint64_t)i * a.S + t;
+        if (g >= a.n_valid) return fr30_unpack(Fr::zero());
         Fr30 x = fr30_unpack(ntt_ld(a.in + g));
         if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
         return x;
