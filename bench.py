@@ -277,6 +277,32 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
         "msm_stage_ms": stage_ms,
     })
 
+    # ---- a prover round's worth of MSMs in one call (typlonk_msm_g1_batch_devptr / _sharded_batch_devptr): sort and
+    # reduction of one MSM hide behind the accumulation of another, and N ranks exchange all nine sums at once.  Not the
+    # headline (one MSM at a time, above), reported next to it because this is how prove() issues its commitments.
+    if not args.msm_only:
+        try:
+            nb = 9
+            ptrs, ms = [full.data_ptr()] * nb, [n - (k % 3) for k in range(nb)]
+            sh.msm_batch_devptr(ptrs, ms)
+            sync_all()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                outs = sh.msm_batch_devptr(ptrs, ms)
+            sync_all()
+            tb = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([tb], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tb = float(t.item())
+            same = bool((np.asarray(outs[0][0]) == np.asarray(out_xy)).all() and outs[0][1] == out_inf)
+            result["msm_batch"] = {"msms": nb, "ms_per_msm": tb / reps / nb * 1e3, "first_equals_single": same}
+        except Exception as e:  # noqa: BLE001 -- a secondary figure must not cost the headline
+            if world > 1:
+                raise                     # inside a collective sequence: let the ranks fail together
+            result["msm_batch_error"] = f"{type(e).__name__}: {e}"
+
     # ---- roofline of the dominant kernel (bucket accumulation), HIP events on the launch stream ----
     # A stand-alone MSM of >= 2^20 terms launches the accumulation once per chunk of ~2^19 terms (capi.hip, msm_enqueue):
     # everything below is PER LAUNCH, as rocprofv3's per-kernel average is (profiles/r0x_kernel_stats_bench_msm_only.csv).

@@ -169,7 +169,7 @@ struct typlonk_ctx {
     int msm_inflight = 4;           // MSMs of a batch in flight at once (TYPLONK_MSM_INFLIGHT, 1..MSM_LANES)
     hipEvent_t lane_evt[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // "scalars ready" marks (MsmQueue::submit)
     // NTT
-    DevBuf ntt_scratch, ntt_io, quot_ext, ops_tmp, prover_mem;
+    DevBuf ntt_scratch, ntt_io, quot_ext, quot_tab, ops_tmp, prover_mem;
     bool prover_busy = false;  // one proof in flight per context (the arena above is shared)
     std::map<std::string, Table> tables;
     uint64_t table_tick = 0;
@@ -1414,7 +1414,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
         (void)hipFree(kv.second.sig_ev);
     }
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
-    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
+    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->quot_tab, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (SortBufs& sb : ws.sb)
             for (DevBuf* b : sb.all()) release(*b);
@@ -1829,7 +1829,12 @@ int quotient_run(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t l
             return rc;
         }
         qa.w_lo = lo.d;
-        qa.w_hi = hi.d;
+        const uint64_t n_hi = 1ull << (log4 - qa.w_h);
+        rc = ensure(ctx, ctx->quot_tab, n_hi * sizeof(Fr));
+        if (rc) return rc;
+        memcpy(qa.beta.v, args->beta, 32);
+        launch_fr_scale(hi.d, n_hi, fe_mul(qa.beta, g), (Fr*)ctx->quot_tab.p, s);
+        qa.bx_hi = (const Fr*)ctx->quot_tab.p;
         // X^n - 1 on the coset: g^n * iota^k - 1 with iota = w_{4n}^n (a primitive 4th root of unity)
         Fr gn = g;
         for (uint32_t i = 0; i < log_n; ++i) gn = fe_sqr(gn);
@@ -1841,12 +1846,11 @@ int quotient_run(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t l
             cur = fe_mul(cur, iota);
         }
     }
-    qa.g = g;
     memcpy(qa.alpha.v, args->alpha, 32);
-    memcpy(qa.beta.v, args->beta, 32);
     memcpy(qa.gamma.v, args->gamma, 32);
     qa.alpha2 = fe_sqr(qa.alpha);
     for (int k = 0; k < 3; ++k) memcpy(qa.k[k].v, args->cosets[k], 32);
+    qa.k0_is_one = qa.k[0] == Fr::one();
     launch_quotient_pointwise(qa, s);
     HIPCHK(hipGetLastError());
     rc = ntt_run(ctx, t_out->d, log4, 1, g_limbs, /*sync=*/false);

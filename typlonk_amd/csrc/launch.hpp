@@ -24,15 +24,17 @@ struct QuotientArgs {
     const Fr* pi;
     const Fr* l0;
     const Fr* w_lo;    // powers of w_{4n}: lo[e & mask] * hi[e >> w_h]
-    const Fr* w_hi;
+    const Fr* bx_hi;   // beta * g * w_hi[j]  (launch_fr_scale per call: beta is per proof)
     Fr* out;
     uint64_t n4;
     uint32_t w_h;
-    Fr g, alpha, alpha2, beta, gamma;
+    uint32_t k0_is_one;  // cosets[0] = 1 (plonk/src/lib.rs: the first wire's coset is H itself): no multiplication
+    Fr alpha, alpha2, beta, gamma;
     Fr k[3];
     Fr zh_inv[4];      // 1 / (g^n * i^k - 1), k = index mod 4
 };
 void launch_fr_fill(Fr* out, uint64_t n, const Fr& value, hipStream_t s);
+void launch_fr_scale(const Fr* in, uint64_t n, const Fr& factor, Fr* out, hipStream_t s);
 void launch_quotient_pointwise(const QuotientArgs& a, hipStream_t s);
 
 // grand product (plonk_ops.hip)

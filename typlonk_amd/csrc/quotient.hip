@@ -46,10 +46,9 @@ __global__ __launch_bounds__(256) void quotient_pointwise_kernel(QuotientArgs a)
     line1 = fe_add(line1, fe_mul(fe_mul(q_ld(a.sel[3] + i), wa), wb));
     line1 = fe_add(line1, q_ld(a.sel[4] + i));
     if (a.pi) line1 = fe_add(line1, q_ld(a.pi + i));  // no public-input polynomial = the zero polynomial
-    // x_i = g * w_{4n}^i from the two-level power table of w_{4n}
-    const Fr x = fe_mul(a.g, fe_mul(q_ld(a.w_lo + (i & ((1ull << a.w_h) - 1))), q_ld(a.w_hi + (i >> a.w_h))));
-    const Fr bx = fe_mul(a.beta, x);
-    Fr l2 = fe_add(fe_add(wa, fe_mul(a.k[0], bx)), a.gamma);
+    // beta * x_i, x_i = g * w_{4n}^i: the two-level power table of w_{4n} with beta * g folded into its upper level
+    const Fr bx = fe_mul(q_ld(a.w_lo + (i & ((1ull << a.w_h) - 1))), q_ld(a.bx_hi + (i >> a.w_h)));
+    Fr l2 = fe_add(fe_add(wa, a.k0_is_one ? bx : fe_mul(a.k[0], bx)), a.gamma);
     l2 = fe_mul(l2, fe_add(fe_add(wb, fe_mul(a.k[1], bx)), a.gamma));
     l2 = fe_mul(l2, fe_add(fe_add(wc, fe_mul(a.k[2], bx)), a.gamma));
     l2 = fe_mul(l2, z);
@@ -64,6 +63,14 @@ __global__ __launch_bounds__(256) void quotient_pointwise_kernel(QuotientArgs a)
     q_st(a.out + i, t);
 }
 
+__global__ __launch_bounds__(256) void fr_scale_kernel(const Fr* in, uint64_t n, Fr factor, Fr* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) q_st(out + i, fe_mul(q_ld(in + i), factor));
+}
+
+void launch_fr_scale(const Fr* in, uint64_t n, const Fr& factor, Fr* out, hipStream_t s) {
+    hipLaunchKernelGGL(fr_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, factor, out);
+}
 void launch_fr_fill(Fr* out, uint64_t n, const Fr& value, hipStream_t s) {
     hipLaunchKernelGGL(fr_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, value);
 }

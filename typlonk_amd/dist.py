@@ -140,6 +140,13 @@ class ShardedMsm:
             return xy, inf
         return allgather_fold(xy, inf, self.device, self.group)
 
+    def msm_batch_devptr(self, d_scalars_list, ms):
+        """several full MSMs over the same SRS (a prover round's commitments): the local partial sums run as one
+        pipelined batch, ONE exchange carries all of them"""
+        if self.native:
+            return self.ctx.msm_sharded_batch_devptr(self.sid, d_scalars_list, ms)
+        return self.fold(self.ctx.msm_batch_devptr(self.sid, d_scalars_list, ms))
+
     def fold(self, points):
         if self.native:
             return self.ctx.comm_fold(points)
