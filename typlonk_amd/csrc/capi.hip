@@ -166,8 +166,18 @@ struct typlonk_ctx {
     static constexpr int MSM_LANES = 4;
     MsmWs ws[MSM_LANES];
     hipStream_t lane[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // lanes 1.. of typlonk_msm_g1_batch* (lane 0 = stream)
-    int msm_inflight = 4;           // MSMs of a batch in flight at once (TYPLONK_MSM_INFLIGHT, 1..MSM_LANES)
+    int msm_inflight = 3;           // MSMs of a batch in flight at once (TYPLONK_MSM_INFLIGHT, 1..MSM_LANES); with the accumulations
+                                    // chained, a fourth lane only adds a sort competing for the same slots (profiles/r03_msm_chain_ab.txt)
     hipEvent_t lane_evt[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // "scalars ready" marks (MsmQueue::submit)
+    hipEvent_t batch_fence = nullptr;   // typlonk_msm_g1_batch_devptr: everything queued before the call (MsmQueue::fence)
+    // Queued MSMs (a batch, a prover round) run their accumulations ONE AFTER THE OTHER, whichever lanes they are on: the
+    // kernel fills every SIMD by itself, so two of them side by side only take turns -- while the sort of the next MSM
+    // and the reduction of the previous one, latency-bound kernels, do hide beside an accumulation.  Without the chain
+    // the lanes move in lockstep (four sorts together, four accumulations together, four reductions together) and
+    // nothing overlaps (profiles/r03_msm_batch_timeline_before.txt).  TYPLONK_MSM_CHAIN=0 switches it off.
+    hipEvent_t accum_chain = nullptr;
+    bool accum_chain_live = false;
+    bool msm_chain = true;
     // NTT
     DevBuf ntt_scratch, ntt_io, quot_ext, quot_tab, ops_tmp, prover_mem;
     bool prover_busy = false;  // one proof in flight per context (the arena above is shared)
@@ -962,11 +972,18 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             // two size classes (the larger half of the buckets: `lanes`, the smaller half: lanes / 2) when lanes were
             // chosen from the load; TYPLONK_MSM_LANES forces one class, TYPLONK_MSM_LANES_SPLIT=0 switches the split off
             const uint32_t split = (lanes >= 2 && !ctx->msm_lanes && ctx->msm_lanes_split) ? (uint32_t)(nb_used / 2) : (uint32_t)nb_used;
+            const bool chain = !standalone && ctx->msm_chain;
+            if (chain && ctx->accum_chain_live) HIPCHK(hipStreamWaitEvent(s, ctx->accum_chain, 0));
             StageTimer st(ctx, "msm_accum", s);
             launch_msm_accum(pts, offsets, sorted, (const uint32_t*)sb.order.p, (uint32_t)nb_used, cap, /*init=*/k > 0, lanes,
                              split, buckets, s);
             launch_msm_heavy(pts, sorted, (uint32_t*)sb.ohist.p, (const uint32_t*)sb.heavy.p,
                              (const uint32_t*)sb.tasks.p, (uint32_t*)sb.hpart.p, buckets, s);
+            if (chain) {
+                if (!ctx->accum_chain) HIPCHK(hipEventCreateWithFlags(&ctx->accum_chain, hipEventDisableTiming));
+                HIPCHK(hipEventRecord(ctx->accum_chain, s));
+                ctx->accum_chain_live = true;
+            }
         }
         if (nch > 1 && k + 2 < nch) HIPCHK(hipEventRecord(ws.ev_acc[k], s));
     }
@@ -1133,6 +1150,7 @@ struct MsmQueue {
     typlonk_ctx* ctx;
     const SrsEntry* srs;
     int lanes, lane_lo, next;
+    hipEvent_t fence = nullptr;  // set: the lanes wait for this mark instead of for everything on the context's stream
     MsmQueue(typlonk_ctx* c, const SrsEntry* s, int first_lane = 0)
         : ctx(c), srs(s), lanes(std::max(1, std::min<int>(c->msm_inflight, typlonk_ctx::MSM_LANES))), lane_lo(0), next(0) {
         set_first_lane(first_lane);
@@ -1158,8 +1176,12 @@ struct MsmQueue {
         if (l) {
             if (!ctx->lane[l]) HIPCHK(hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
             if (!ctx->lane_evt[l]) HIPCHK(hipEventCreateWithFlags(&ctx->lane_evt[l], hipEventDisableTiming));
-            HIPCHK(hipEventRecord(ctx->lane_evt[l], ctx->stream));
-            HIPCHK(hipStreamWaitEvent(ctx->lane[l], ctx->lane_evt[l], 0));
+            if (fence) {
+                HIPCHK(hipStreamWaitEvent(ctx->lane[l], fence, 0));
+            } else {
+                HIPCHK(hipEventRecord(ctx->lane_evt[l], ctx->stream));
+                HIPCHK(hipStreamWaitEvent(ctx->lane[l], ctx->lane_evt[l], 0));
+            }
             st = ctx->lane[l];
         }
         return msm_enqueue(ctx, ws, st, *srs, d_scalars + off, ml, out_xy, out_inf, standalone);
@@ -1188,6 +1210,11 @@ int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, c
     prof_begin(ctx);
     ProfilingOff prof_off(ctx);  // stage events are per call
     MsmQueue q(ctx, srs);
+    // all scalars exist when the call is made: the lanes wait for what is on the context's stream NOW, not for the
+    // MSMs of this batch that lane 0 (the context's stream itself) receives in the meantime
+    if (!ctx->batch_fence) HIPCHK(hipEventCreateWithFlags(&ctx->batch_fence, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->batch_fence, ctx->stream));
+    q.fence = ctx->batch_fence;
     int rc = TYPLONK_OK;
     for (size_t k = 0; k < count && !rc; ++k)
         rc = q.submit((const Fr*)d_scalars[k], m[k], out_xy + 12 * k, out_inf + k, /*standalone=*/count == 1);
@@ -1380,6 +1407,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_STAGGER")) ctx->msm_stagger = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_HOST_PLANES")) ctx->msm_host_planes = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_SIDE_PRIO")) ctx->msm_side_prio = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_MSM_CHAIN")) ctx->msm_chain = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES_SPLIT")) ctx->msm_lanes_split = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
         const int l = atoi(e);
@@ -1432,6 +1460,8 @@ void typlonk_destroy(typlonk_ctx* ctx) {
         if (l) (void)hipStreamDestroy(l);
     for (hipEvent_t e : ctx->lane_evt)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->batch_fence) (void)hipEventDestroy(ctx->batch_fence);
+    if (ctx->accum_chain) (void)hipEventDestroy(ctx->accum_chain);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
