@@ -138,9 +138,9 @@ int typlonk_msm_g1_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scala
                           uint64_t out_xy[12], uint8_t* out_inf);
 
 /* `count` independent MSMs over the same SRS (prove() issues them in groups: the three wire
- * commitments plonk/src/proof.rs:107-110, the openings :147-175, the quotient slices :181).  Up to four
- * are kept in flight on separate workspaces/streams (TYPLONK_MSM_INFLIGHT=1..4) so one MSM's sort and reduction
- * tail overlap the others' accumulation.  d_scalars[k]: device pointer to m[k] Fr elements; out_xy: count*12 limbs; out_inf: count. */
+ * commitments plonk/src/proof.rs:107-110, the openings :147-175, the quotient slices :181).  Three
+ * are kept in flight on separate workspaces/streams (TYPLONK_MSM_INFLIGHT=1..4), their accumulations one after the
+ * other, so one MSM's sort and reduction tail run beside another's accumulation.  d_scalars[k]: device pointer to m[k] Fr elements; out_xy: count*12 limbs; out_inf: count. */
 int typlonk_msm_g1_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m,
                                 size_t count, uint64_t* out_xy, uint8_t* out_inf);
 

@@ -38,6 +38,7 @@ def test_two_ranks_sharded_msm_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["metric"] == "msm_g1_adds_per_s"
     assert d["parity"]["full_commit_identity"] is True and d["value"] is not None
     assert "index-sharded x2" in d["config"]["parallelism"]
+    assert d["msm_batch"]["msms"] == 9 and d["msm_batch"]["first_equals_single"] is True
 
 
 def test_one_rank_through_rccl_all_gather():

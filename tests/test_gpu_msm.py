@@ -244,6 +244,46 @@ def test_batch_matches_individual_msms(ctx):
     ctx.srs_free(sid)
 
 
+@pytest.mark.parametrize("chain,inflight", [("1", "3"), ("0", "4"), ("1", "1"), ("0", "2"), ("1", "4")])
+def test_batch_scheduling_variants_give_identical_points(built, chain, inflight, monkeypatch):
+    """How a batch is scheduled -- accumulations chained one after the other across the lanes or free-running
+    (TYPLONK_MSM_CHAIN), one to four MSMs in flight (TYPLONK_MSM_INFLIGHT) -- must not change a bit: nine table-mode
+    MSMs at 2^16 (prove()'s lengths n, n - 1, n - 3, one empty) against commit(p) == [p(s)]G (kzg/src/lib.rs:102-105),
+    twice in a row on the same context (lanes and the chain event are reused)"""
+    import typlonk_amd
+    from oracle import coracle as CO
+
+    monkeypatch.setenv("TYPLONK_MSM_CHAIN", chain)
+    monkeypatch.setenv("TYPLONK_MSM_INFLIGHT", inflight)
+    c2 = typlonk_amd.Context(0)
+    try:
+        n = 1 << 16
+        s_limbs = np.array(O.fr_to_mont_limbs(0x5EED), dtype=np.uint64)
+        sid = c2.srs_generate(s_limbs, n + 3)
+        c2.srs_precompute(sid, 0)
+        rng = np.random.default_rng(int(chain) * 10 + int(inflight))
+        ms = [n, n - 1, n - 1, 0, n - 3, n, n - 1, 4097, n]
+        bufs, exp = [], []
+        for m in ms:
+            sc = rng.integers(0, 1 << 63, size=(max(m, 1), 4), dtype=np.uint64) * 2
+            sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+            b = c2.alloc(max(m, 1))
+            b.upload(sc)
+            bufs.append(b)
+            exp.append(CO.g1_mul_generator(CO.poly_eval(sc[:m], s_limbs)) if m else (None, 1))
+        for _ in range(2):
+            got = c2.msm_batch_devptr(sid, [b.devptr for b in bufs], ms)
+            for (gx, gi), (ex, ei), m in zip(got, exp, ms):
+                assert gi == ei and (m == 0 or (gx == ex).all()), (chain, inflight, m)
+            # a stand-alone MSM between two batches (does not take part in the chain)
+            one = c2.msm_devptr(sid, bufs[0].devptr, n)
+            assert (one[0] == exp[0][0]).all() and one[1] == exp[0][1]
+        for b in bufs:
+            b.free()
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("name", ["ones", "repeated", "alternating", "short", "two_values"])
 def test_adversarial_scalars_at_2_16_use_heavy_bucket_tasks(ctx, name):
     """SURVEY section 8d adversarial sets at a size where a single bucket receives up to m entries: the
