@@ -372,19 +372,24 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
     for _ in range(2):
         ctx.ntt_devptr(v.data_ptr(), log_n)
     torch.cuda.synchronize()
-    reps, kern = 10, 0.0
+    # forward and inverse transforms alternate (a round trip leaves the data unchanged); they run on different kernels
+    # from 2^20 up (capi.hip ntt_run: forward on 8 x 32-bit words, inverse on 9 x 30-bit limbs), so both are reported
+    reps, kdir = 10, [0.0, 0.0]
     t1 = time.perf_counter()
     for i in range(reps):
         ctx.ntt_devptr(v.data_ptr(), log_n, inverse=bool(i & 1))
-        kern += prof_ms(ctx, "ntt_")
+        kdir[i & 1] += prof_ms(ctx, "ntt_")
     torch.cuda.synchronize()
     tn = (time.perf_counter() - t1) / reps
-    kern_s = kern / reps * 1e-3
+    kern = kdir[0] + kdir[1]
+    kern_s = kdir[0] / (reps // 2) * 1e-3     # the VALU figures below describe the forward kernel (profiles/r03_isa_ntt.json)
     # Fr multiplications the kernels execute per transform: n/2 log2(n) butterflies less the
     # twiddle-1 ones of the last two stages of every pass, plus one inter-pass / scaling factor per element and pass
     fr_muls = _isa("r03_isa_ntt.json", f"fr_mul_per_transform_2_{log_n}", n * (log_n / 2.0 + 1))
+    mean_s = kern / reps * 1e-3
     result["ntt"] = {"log_n": log_n, "ms": tn * 1e3, "kernel_ms": kern / reps,
-                     "algorithmic_GBps": 64.0 * n / kern_s / 1e9, "frac_of_hbm_peak": 64.0 * n / kern_s / 1e9 / HBM_PEAK_GBS,
+                     "forward_kernel_ms": kdir[0] / (reps // 2), "inverse_kernel_ms": kdir[1] / (reps // 2),
+                     "algorithmic_GBps": 64.0 * n / mean_s / 1e9, "frac_of_hbm_peak": 64.0 * n / mean_s / 1e9 / HBM_PEAK_GBS,
                      "valu": {"achieved": fr_muls / kern_s, "peak": FR_MUL_MULTIPLIER_CEILING, "unit": "Fr mul/s",
                               "frac": fr_muls / kern_s / FR_MUL_MULTIPLIER_CEILING,
                               "fr_mul_per_transform": fr_muls,

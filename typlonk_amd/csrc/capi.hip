@@ -208,7 +208,7 @@ struct typlonk_ctx {
     int prover_rounds_active = 0;  // > 0 while a typlonk_prover_round* call is running (ProverRound)
     bool ntt_big_tiles = true;     // TYPLONK_NTT_BIG=0: always 1024-element tiles (three passes at 2^20)
     bool ntt_full_tables = true;   // TYPLONK_NTT_FULL_TABLES=0: compose twiddles / coset powers from two-level tables
-    int ntt_fr30 = 1;              // TYPLONK_NTT_FR30: 0 = off, 1 = 9 x 30-bit butterflies (fr30.hpp) up to 2^19 and for inverse transforms from 2^21,
+    int ntt_fr30 = 1;              // TYPLONK_NTT_FR30: 0 = off, 1 = 9 x 30-bit butterflies (fr30.hpp) up to 2^20 and for every inverse transform,
                                    // 2 = for every transform (the 4096-element tiles of 2^20 are then not used)
     uint32_t ntt_full_max_log = 24;
     int ntt_tile_log = 0;          // TYPLONK_NTT_TILE (measurement): tiles of the two-pass 2^20 transform, see ntt_run
@@ -536,7 +536,8 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     uint32_t ks[4], P;
     // (not inside a prover round: there the 144 KiB workgroups crowd out the LDS of the MSM lanes' sort kernels running
     // beside them -- prove() 38.1 -> 38.3 ms in the same-box A/B)
-    bool big = ctx->ntt_big_tiles && log_n == 20 && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
+    // (forward only: an inverse 2^20 transform is 4 % faster in three passes of the 30-bit kernel, 0.148 against 0.153 ms)
+    bool big = ctx->ntt_big_tiles && log_n == 20 && (!inverse || ctx->ntt_fr30 == 0) && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
     if (big && ctx->ntt_fr30 == 2 && ctx->ntt_full_tables) big = false;  // 36 B per element: 4096 of them do not fit
     // log2 of the tile capacity; TYPLONK_NTT_TILE=11 tries 2048-element tiles (two columns, two workgroups per CU) for the
     // two-pass 2^20 transform
@@ -558,10 +559,11 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     // measured: the 9 x 30-bit kernel is 9-12 % faster up to 2^19; at 2^20 the two-pass 4096-element
     // tiles of the 8 x 32 kernel win, and from 2^21 on the 36-B LDS elements cost a workgroup per CU (3 instead of 4)
     // and a forward transform pays one extra reducing multiplication per element: mode 1 (default) stops at 2^19
-    // Round 3 (radix-4 groups in both kernels, profiles/r03_ntt_fr30_modes.txt): from 2^21 on an INVERSE transform is 4-9 %
-    // faster on the 30-bit kernel (its n^-1 / coset factor closes the last pass for free), a forward one still is not
+    // Round 3 (radix-4 groups in both kernels, profiles/r03_ntt_fr30_modes.txt): an INVERSE transform is 4-9 % faster on the
+    // 30-bit kernel at every size (its n^-1 / coset factor closes the last pass for free), a forward one from 2^21 on is
+    // not; at 2^20 a forward transform takes the two-pass big tiles when they are allowed, the 30-bit kernel otherwise
     const bool want30 = ctx->ntt_fr30 != 0 && ctx->ntt_full_tables && !big &&
-                        (ctx->ntt_fr30 == 2 || log_n <= 19 || (inverse && log_n >= 21));
+                        (ctx->ntt_fr30 == 2 || log_n <= 20 || inverse);
 
     // coset / scaling tables (the full tables of the 8 x 32 kernel are not built when the other kernel will run)
     Table pre_lo{}, pre_hi{}, post_lo{}, post_hi{}, scale{}, pre_full{}, post_full{};
