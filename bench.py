@@ -580,54 +580,69 @@ def bench_cpu(args, ctx, sh, full, n, log_n, secret, out_xy, out_inf, result) ->
         from oracle import cpu_prover as CP
         from typlonk_amd.circuits import SquaringChain
 
-        lg = min(16, log_n)
-        chain = SquaringChain(ctx, lg, keep_host=True)
-        try:
-            sid16 = ctx.srs_generate(secret, (1 << lg) + 3)
-            ctx.srs_precompute(sid16, 20)
-            ch = [fr_mont_limbs(0x1234567 + k) for k in range(4)]
-            run = lambda: ctx.prove(sid16, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731
-                                    lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]))
-            run()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                gp = run()
-            torch.cuda.synchronize()
-            t_gpu = (time.perf_counter() - t1) / 3 * 1e3
-            inputs = chain.host_inputs()
-            sxy, sinf = ctx.srs_download(sid16, 0, (1 << lg) + 3)
-            CP.prove(lg, inputs, sxy, sinf, ch)                       # warm-up (OpenMP team, page faults)
-            t1 = time.perf_counter()
-            cp = CP.prove(lg, inputs, sxy, sinf, ch)
-            t_cpu = (time.perf_counter() - t1) * 1e3
-            same = all((np.asarray(a[0]) == np.asarray(b[0])).all() and a[1] == b[1]
-                       for k in ("commit", "t_commit", "witness") for a, b in zip(gp[k], cp[k]))
-            same = same and bool((gp["z_commit"][0] == cp["z_commit"][0]).all())
-            same = same and all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(gp["evals"], cp["evals"]))
-            result["cpu_fair"].update({f"prove_ms_2_{lg}": t_cpu, f"gpu_prove_ms_2_{lg}": t_gpu,
-                                       f"prove_speedup_2_{lg}": t_cpu / t_gpu, "prove_stage_ms": cp["stage_ms"],
-                                       "prove_equals_gpu": bool(same), "prove_threads": cp["threads"]})
-            result["parity"]["prove_vs_fair_cpu_prover"] = bool(same)
-            ctx.srs_free(sid16)
-        finally:
-            chain.free()
+        # ... and at the headline size itself (one CPU proof, ~25 s on 128 cores): the measured denominator of the
+        # north-star's ">= 10x prove()" -- no extrapolation
+        for lg in sorted({min(16, log_n), log_n}):
+            chain = SquaringChain(ctx, lg, keep_host=True)
+            try:
+                own_srs = lg != log_n or sh.world != 1     # the headline SRS (c = 20 tables) serves the headline size
+                sid_l = sh.sid
+                if own_srs:
+                    sid_l = ctx.srs_generate(secret, (1 << lg) + 3)
+                    ctx.srs_precompute(sid_l, 20)
+                ch = [fr_mont_limbs(0x1234567 + k) for k in range(4)]
+                run = lambda: ctx.prove(sid_l, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731,B023
+                                        lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]))                   # noqa: B023
+                # the GPU has idled through the CPU legs above: proofs for half a second bring its clocks back up before
+                # the timed ones (without this the same proof reads 51 ms instead of 37 at 2^20)
+                t1 = time.perf_counter()
+                while time.perf_counter() - t1 < 0.5:
+                    run()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    gp = run()
+                torch.cuda.synchronize()
+                t_gpu = (time.perf_counter() - t1) / 3 * 1e3
+                inputs = chain.host_inputs()
+                sxy, sinf = ctx.srs_download(sid_l, 0, (1 << lg) + 3)
+                if lg <= 16:
+                    CP.prove(lg, inputs, sxy, sinf, ch)                   # warm-up (OpenMP team, page faults)
+                t1 = time.perf_counter()
+                cp = CP.prove(lg, inputs, sxy, sinf, ch)
+                t_cpu = (time.perf_counter() - t1) * 1e3
+                same = all((np.asarray(a[0]) == np.asarray(b[0])).all() and a[1] == b[1]
+                           for k in ("commit", "t_commit", "witness") for a, b in zip(gp[k], cp[k]))
+                same = same and bool((gp["z_commit"][0] == cp["z_commit"][0]).all())
+                same = same and all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(gp["evals"], cp["evals"]))
+                result["cpu_fair"].update({f"prove_ms_2_{lg}": t_cpu, f"gpu_prove_ms_2_{lg}": t_gpu,
+                                           f"prove_speedup_2_{lg}": t_cpu / t_gpu, f"prove_stage_ms_2_{lg}": cp["stage_ms"],
+                                           f"prove_equals_gpu_2_{lg}": bool(same), "prove_threads": cp["threads"]})
+                result["parity"]["prove_vs_fair_cpu_prover"] = bool(same) and result["parity"].get("prove_vs_fair_cpu_prover", True)
+                if own_srs:
+                    ctx.srs_free(sid_l)
+            finally:
+                chain.free()
     # the north-star's ">= 10x prove() over the CPU reference"
     if "prove_ms" in result:
         msm_terms = 13 * n
-        fair_prove_s = None
-        key = f"prove_ms_2_{min(16, log_n)}"
-        if key in result["cpu_fair"]:
+        fair_prove_s, fair_note = None, "not measured"
+        if f"prove_ms_2_{log_n}" in result["cpu_fair"]:
+            fair_prove_s = result["cpu_fair"][f"prove_ms_2_{log_n}"] * 1e-3
+            fair_note = (f"measured end to end at 2^{log_n} on {result['cpu_fair'].get('prove_threads')} threads, same circuit, "
+                         "witness and challenges as the GPU proof, every proof element equal")
+        elif f"prove_ms_2_{min(16, log_n)}" in result["cpu_fair"]:
             # a prove() is ~linear in n on the CPU (bucket MSMs and NTTs dominate): scale the measured 2^16 proof
-            fair_prove_s = result["cpu_fair"][key] * 1e-3 * (n / (1 << min(16, log_n)))
+            fair_prove_s = result["cpu_fair"][f"prove_ms_2_{min(16, log_n)}"] * 1e-3 * (n / (1 << min(16, log_n)))
+            fair_note = (f"measured end to end at 2^{min(16, log_n)} on {result['cpu_fair'].get('prove_threads')} threads, "
+                         f"scaled linearly to 2^{log_n}")
         result["prove_vs_cpu"] = {
             "gpu_prove_ms": result["prove_ms"],
             "cpu_reference_path_s": msm_terms / (ms / tc) + result["cpu_reference_quotient"][f"extrapolated_s_2^{log_n}"],
             "cpu_reference_path_parts": "13 MSMs at the measured reference-path rate + the extrapolated schoolbook quotient",
             "cpu_reference_cores": 1,
             "cpu_fair_prove_s": fair_prove_s,
-            "cpu_fair_note": (f"measured end to end at 2^{min(16, log_n)} on {result['cpu_fair'].get('prove_threads')} threads, "
-                              f"scaled linearly to 2^{log_n}") if fair_prove_s else "not measured",
+            "cpu_fair_note": fair_note,
             "cpu_fair_13_msms_s": 13 * tf, "cpu_all_cores": f_thr,
             "speedup_vs_reference_path": (msm_terms / (ms / tc) + result["cpu_reference_quotient"][f"extrapolated_s_2^{log_n}"])
                                          / (result["prove_ms"] * 1e-3),

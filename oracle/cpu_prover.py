@@ -53,6 +53,44 @@ def lincomb(polys, scalars, n, constant=None):
     return out
 
 
+def quotient(log_n: int, wires, z, pi, sel, sig, alpha: int, beta: int, gamma: int, ks, threads: int = 0, stage=None):
+    """t(X) as plonk::proof::quotient_polynomial defines it (proof.rs:292-375), computed the way the GPU path computes it:
+    every input polynomial (n coefficients, Montgomery limbs) evaluated on the coset 7 H_4n, the formula applied point
+    by point with the division by X^n - 1, one inverse coset transform.  Returns the 4n coefficients (the top n are zero
+    exactly when the numerator vanishes on H, i.e. for a satisfying witness).  alpha / beta / gamma / ks: integers."""
+    lib = CO.lib()
+    n = 1 << log_n
+    stage = {} if stage is None else stage
+    t0 = time.perf_counter()
+
+    def mark(name):
+        nonlocal t0
+        t = time.perf_counter()
+        stage[name] = stage.get(name, 0.0) + (t - t0) * 1e3
+        t0 = t
+
+    k_l = np.ascontiguousarray(np.stack([_limbs(k) for k in ks]))
+    l0 = np.tile(_limbs(pow(n, -1, R)), (n, 1))                                                         # utils.rs:150-159
+    g7 = _limbs(7)
+
+    def extend(p):
+        buf = np.zeros((4 * n, 4), dtype=np.uint64)
+        buf[:n] = np.asarray(p, dtype=np.uint64).reshape(n, 4)
+        return CO.ntt(buf, log_n + 2, coset=g7, threads=threads)
+
+    ext = [extend(p) for p in list(wires) + [z, pi] + list(sel) + list(sig) + [l0]]
+    mark("ntt")
+    t_ev = np.zeros((4 * n, 4), dtype=np.uint64)
+    rc = lib.oracle_quotient_pointwise(_ptrs(ext), C.c_uint32(log_n), _p64(_limbs(alpha)), _p64(_limbs(beta)), _p64(_limbs(gamma)),
+                                       _p64(k_l), _p64(g7), _p64(t_ev))
+    assert rc == 0
+    del ext
+    mark("quotient_pointwise")
+    t = CO.ntt(t_ev, log_n + 2, inverse=True, coset=g7, threads=threads)
+    mark("ntt")
+    return t
+
+
 def prove(log_n: int, inputs: dict, srs_xy, srs_inf, challenges, threads: int = 0):
     """inputs = SquaringChain.host_inputs() (wire / selector / sigma EVALUATIONS, Montgomery limbs; public inputs [0]);
     challenges = [beta, gamma, alpha, zeta] as limb arrays (what bench.py injects into the GPU prover as well).
@@ -103,25 +141,10 @@ def prove(log_n: int, inputs: dict, srs_xy, srs_inf, challenges, threads: int = 
     # ---- round 3: quotient on the coset 7 H_4n (:292-375) ----------------------------------------------------------
     sel = [intt(np.ascontiguousarray(s, dtype=np.uint64).reshape(n, 4)) for s in inputs["selectors"]]   # builder.rs:84-88
     sig = [intt(s) for s in sig_ev]                                                                     # proof.rs:334-338
+    mark("ntt")
     pi = np.zeros((n, 4), dtype=np.uint64)                                                              # public inputs [0]
-    l0 = np.tile(_limbs(pow(n, -1, R)), (n, 1))                                                         # utils.rs:150-159
-    g7 = _limbs(7)
-
-    def extend(p):
-        buf = np.zeros((4 * n, 4), dtype=np.uint64)
-        buf[:n] = p
-        return CO.ntt(buf, log_n + 2, coset=g7, threads=threads)
-
-    ext = [extend(p) for p in wires + [z, pi] + sel + sig + [l0]]
-    mark("ntt")
-    t_ev = np.zeros((4 * n, 4), dtype=np.uint64)
-    rc = lib.oracle_quotient_pointwise(_ptrs(ext), C.c_uint32(log_n), _p64(_limbs(alpha)), _p64(_limbs(beta)), _p64(_limbs(gamma)),
-                                       _p64(k_l), _p64(g7), _p64(t_ev))
-    assert rc == 0
-    del ext
-    mark("quotient_pointwise")
-    t = CO.ntt(t_ev, log_n + 2, inverse=True, coset=g7, threads=threads)
-    mark("ntt")
+    t = quotient(log_n, wires, z, pi, sel, sig, alpha, beta, gamma, ks, threads=threads, stage=stage)
+    t0 = time.perf_counter()
     assert not t[3 * n:].any(), "the quotient has degree >= 3n: the witness does not satisfy the circuit"
     t_sl = [t[0:n], t[n:2 * n], t[2 * n:3 * n]]
     # ---- openings (:147-175; kzg/src/lib.rs:55-64) -------------------------------------------------------------------

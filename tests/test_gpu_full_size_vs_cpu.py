@@ -1,0 +1,156 @@
+"""The prover's device-side steps at BASELINE's full sizes (configs 2-3: n = 2^16, 2^20; quotient domain 4n = 2^22)
+against the C oracle, word for word -- the small-n tests (test_gpu_quotient.py, test_gpu_prover_ops.py) compare with the
+reference-faithful Python restatements, which stop at n = 2^8..2^13:
+
+  * quotient_polynomial (plonk/src/proof.rs:292-375): all 4n coefficients equal the CPU coset-NTT quotient of
+    oracle/cpu_prover.py (itself held to the schoolbook restatement in tests/test_oracle.py), with and without a loaded
+    circuit, plus the defining identity t(x) (x^n - 1) = numerator(x) at points of the coset, by Horner's rule;
+  * the grand product Z (permutation/src/proving.rs:7-31) against oracle_grand_product;
+  * KzgScheme::open's Horner value and quotient (kzg/src/lib.rs:55-61) against oracle_poly_div_linear;
+  * a whole proof at n = 2^16 against the fair CPU prover: every commitment, witness and evaluation.
+Inputs are seeded random polynomials (any input is a valid input of these functions; a satisfying witness is used for the
+whole proof)."""
+import numpy as np
+import pytest
+
+from helpers import O
+
+pytestmark = pytest.mark.gpu
+
+R = O.R
+ALPHA, BETA, GAMMA = 0x1234567DEADBEEF, 0xABCDEF0123456789ABCDEF, 0x55AA55AA77
+KS = (1, 7, 13)
+
+
+def _limbs(v):
+    return np.array(O.fr_to_mont_limbs(v % R), dtype=np.uint64)
+
+
+def _rand(rng, n):
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)   # < 2^254 < r: every limb pattern is a Montgomery residue
+    return a
+
+
+def _up(ctx, arr):
+    b = ctx.alloc(arr.shape[0])
+    b.upload(arr)
+    return b
+
+
+@pytest.mark.parametrize("log_n", [16, 20])
+def test_quotient_equals_the_cpu_coset_ntt_quotient(ctx, log_n):
+    from oracle import coracle as CO
+    from oracle import cpu_prover as CP
+
+    n = 1 << log_n
+    rng = np.random.default_rng(900 + log_n)
+    polys = [_rand(rng, n) for _ in range(13)]          # a b c | Z | PI | q_l q_r q_o q_m q_c | s0 s1 s2
+    # edge rows: zeros, r - 1, a short polynomial (trailing zeros, as DensePolynomial trims them)
+    polys[0][:5] = 0
+    polys[1][7] = _limbs(R - 1)
+    polys[9][n // 2:] = 0
+    wires, z, pi, sel, sig = polys[0:3], polys[3], polys[4], polys[5:10], polys[10:13]
+    exp = CP.quotient(log_n, wires, z, pi, sel, sig, ALPHA, BETA, GAMMA, KS)
+    bufs = [_up(ctx, p) for p in polys]
+    t_out = ctx.alloc(4 * n)
+    args = (_limbs(ALPHA), _limbs(BETA), _limbs(GAMMA), [_limbs(k) for k in KS], t_out)
+    ctx.quotient_dev(log_n, bufs[0:3], bufs[3], bufs[5:10], bufs[10:13], bufs[4], *args)
+    got = t_out.download()
+    assert (got == exp).all()
+    # the same through a loaded circuit (per-circuit coset evaluations cached in HBM), twice: the cache is not consumed
+    cid = ctx.circuit_load(log_n, bufs[5:10], bufs[10:13])
+    for _ in range(2):
+        t_out.zero()
+        ctx.quotient_dev(log_n, bufs[0:3], bufs[3], None, None, bufs[4], *args, circuit=cid)
+        assert (t_out.download() == exp).all()
+    ctx.circuit_free(cid)
+    # independently of any transform code: at points x_k = 7 w_4n^k of the coset, t(x_k) (x_k^n - 1) = numerator(x_k) with
+    # every polynomial evaluated by Horner's rule (oracle_poly_eval) and the formula in Python integers
+    w, w4 = O.domain_root(log_n), O.domain_root(log_n + 2)
+    for k in (0, 1, n + 3, 4 * n - 1):
+        xk = 7 * pow(w4, k, R) % R
+        ev = lambda p, at=xk: O.fr_from_mont_limbs([int(v) for v in CO.poly_eval(p, _limbs(at))])
+        a, b, c, zz, pp = ev(wires[0]), ev(wires[1]), ev(wires[2]), ev(z), ev(pi)
+        q = [ev(sx) for sx in sel]
+        s = [ev(gx) for gx in sig]
+        zw = ev(z, xk * w % R)
+        l0 = (pow(xk, n, R) - 1) * pow(n * (xk - 1) % R, -1, R) % R
+        line1 = (q[0] * a + q[1] * b - q[2] * c + q[3] * a * b + q[4] + pp) % R
+        l2 = (a + BETA * KS[0] * xk + GAMMA) * (b + BETA * KS[1] * xk + GAMMA) % R * (c + BETA * KS[2] * xk + GAMMA) % R * zz % R
+        l3 = (a + BETA * s[0] + GAMMA) * (b + BETA * s[1] + GAMMA) % R * (c + BETA * s[2] + GAMMA) % R * zw % R
+        num = (line1 + ALPHA * (l2 - l3) + ALPHA * ALPHA * (zz - 1) * l0) % R
+        assert ev(got) * (pow(xk, n, R) - 1) % R == num, k
+    for bf in bufs + [t_out]:
+        bf.free()
+
+
+@pytest.mark.parametrize("log_n", [16, 20, 22])
+def test_grand_product_equals_the_c_oracle(ctx, log_n):
+    import ctypes as C
+    from oracle import coracle as CO
+    from oracle.cpu_prover import _p64, _ptrs
+
+    n = 1 << log_n
+    rng = np.random.default_rng(300 + log_n)
+    wires = [_rand(rng, n) for _ in range(3)]
+    sigma = [_rand(rng, n) for _ in range(3)]
+    k_l = np.ascontiguousarray(np.stack([_limbs(k) for k in KS]))
+    exp = np.zeros((n, 4), dtype=np.uint64)
+    last = np.zeros(4, dtype=np.uint64)
+    rc = CO.lib().oracle_grand_product(_ptrs(wires), _ptrs(sigma), _p64(_limbs(BETA)), _p64(_limbs(GAMMA)), _p64(k_l),
+                                       C.c_uint32(log_n), _p64(exp), _p64(last))
+    assert rc == 0
+    wb, sb = [_up(ctx, w) for w in wires], [_up(ctx, s) for s in sigma]
+    z = ctx.alloc(n)
+    ctx.grand_product_dev(log_n, wb, sb, _limbs(BETA), _limbs(GAMMA), [_limbs(k) for k in KS], z)
+    assert (z.download() == exp).all()
+    for bf in wb + sb + [z]:
+        bf.free()
+
+
+@pytest.mark.parametrize("m", [1 << 20, (1 << 20) - 1, (1 << 22) - 3])
+def test_open_equals_the_c_oracle_at_full_size(ctx, m):
+    from oracle import coracle as CO
+
+    rng = np.random.default_rng(m & 0xFFFF)
+    p = _rand(rng, m)
+    p[m - 1] = _limbs(R - 1)
+    zpt = _limbs(0xDEADBEEFCAFEF00D0123456789ABCDEF)
+    q_exp, y_exp = CO.poly_div_linear(p, zpt)
+    pb, qb = _up(ctx, p), ctx.alloc(m)
+    y = ctx.open_dev(pb, m, zpt, qb)
+    assert (y == y_exp).all()
+    assert (qb.download(0, m - 1) == q_exp).all()
+    pb.free()
+    qb.free()
+
+
+@pytest.mark.parametrize("log_n", [16, 18, 20])
+def test_whole_proof_equals_the_fair_cpu_prover(ctx, log_n):
+    """BASELINE config 2 ("2^16-constraint synthetic mul-chain, single MI355X MSM+NTT, bit-exact vs CPU"): the squaring
+    chain's proof -- 7 commitments, 6 witnesses, 6 evaluations -- from the GPU prover and from the all-core CPU prover
+    (oracle/cpu_prover.py: same rounds, NTT quotient, bucket MSMs) under the same injected challenges; and the same at
+    2^18 and at config 3's 2^20 (the CPU proof takes ~25 s on the GPU box's 128 cores)"""
+    from oracle import cpu_prover as CP
+    from typlonk_amd.circuits import SquaringChain
+
+    n = 1 << log_n
+    s_limbs = _limbs(2)
+    sid = ctx.srs_generate(s_limbs, n + 3)
+    srs_xy, srs_inf = ctx.srs_download(sid)
+    ctx.srs_precompute(sid, 0)
+    chain = SquaringChain(ctx, log_n, keep_host=True)
+    ch = [_limbs(0x1234567 + k) for k in range(4)]
+    proof = ctx.prove(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,
+                      lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]))
+    ref = CP.prove(log_n, chain.host_inputs(), srs_xy, srs_inf, ch)
+    for key in ("commit", "t_commit", "witness"):
+        assert len(proof[key]) == len(ref[key])
+        for (gx, gi), (ex, ei) in zip(proof[key], ref[key]):
+            assert (np.asarray(gx) == np.asarray(ex)).all() and int(gi) == int(ei), key
+    assert (np.asarray(proof["z_commit"][0]) == np.asarray(ref["z_commit"][0])).all()
+    for g, e in zip(proof["evals"], ref["evals"]):
+        assert (np.asarray(g) == np.asarray(e)).all()
+    chain.free()
+    ctx.srs_free(sid)
