@@ -119,3 +119,46 @@ def test_msm_results_identical_with_and_without_profiling(ctx):
     assert any(nm.startswith("msm_accum") for nm in names)
     assert g1_unpack_one(a[0], a[1]) is not None
     ctx.srs_free(sid)
+
+
+def test_heavy_bucket_shapes_stay_within_reach_of_the_uniform_case(built):
+    """Performance guard, loose on purpose (profiles/r03_heavy_tasks_ab.txt): scalar sets that pile entries on a few
+    buckets -- 64 distinct values, or tables whose top window is 2 bits wide -- used to cost 55x / 25x a uniform MSM of
+    the same size (one thread per 512-entry task, all folds in one workgroup); with a wavefront per task they cost
+    1.2-2x.  Fails only if the cliff comes back (> 12x)."""
+    import time
+
+    import torch
+
+    import typlonk_amd
+    from bench import fr_mont_limbs, synthetic_scalars
+
+    ctx = typlonk_amd.Context(0)
+    try:
+        m = 1 << 16
+        dev = torch.device("cuda", 0)
+        uni = synthetic_scalars(m, 5, dev)
+        rep = uni.clone()
+        rep[:] = uni[torch.arange(m, device=dev) >> 10 << 10]      # 64 distinct scalars, 1024 copies each
+
+        def ms(sid, sc):
+            for _ in range(3):
+                ctx.msm_devptr(sid, sc.data_ptr(), m)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ctx.msm_devptr(sid, sc.data_ptr(), m)
+            return (time.perf_counter() - t0) / 10 * 1e3
+
+        auto = ctx.srs_generate(fr_mont_limbs(2), m + 3)
+        ctx.srs_precompute(auto, 0)
+        thin = ctx.srs_generate(fr_mont_limbs(2), m + 3)
+        ctx.srs_precompute(thin, 18)
+        base = ms(auto, uni)
+        assert ms(auto, rep) < 12 * base
+        assert ms(thin, uni) < 12 * base
+        # and the points are the same whichever path sums them
+        a = ctx.msm_devptr(auto, rep.data_ptr(), m)
+        b = ctx.msm_devptr(thin, rep.data_ptr(), m)
+        assert (a[0] == b[0]).all() and a[1] == b[1]
+    finally:
+        ctx.close()

@@ -178,6 +178,7 @@ struct typlonk_ctx {
     hipEvent_t accum_chain = nullptr;
     bool accum_chain_live = false;
     bool msm_chain = true;
+    uint32_t msm_cap_min = 32;    // TYPLONK_MSM_CAP_MIN: smallest heavy-bucket threshold (round 2: 512)
     // NTT
     DevBuf ntt_scratch, ntt_io, quot_ext, quot_tab, ops_tmp, prover_mem;
     bool prover_busy = false;  // one proof in flight per context (the arena above is shared)
@@ -909,10 +910,15 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if ((rc = ensure(ctx, sb.order, nb * 4))) return rc;
         if ((rc = ensure(ctx, sb.ohist, 516 * 4))) return rc;
         // heavy-bucket splitting: cap = entries one thread may sum; at most total/cap heavy buckets/tasks
-        const uint32_t cap = (uint32_t)std::max<uint64_t>(512, 4 * ((total + nb_used - 1) / nb_used));
-        const uint64_t max_tasks = total / cap + 2;
-        if ((rc = ensure(ctx, sb.heavy, max_tasks * 12))) return rc;
-        if ((rc = ensure(ctx, sb.tasks, max_tasks * 8))) return rc;
+        // 8 x the mean, at least 32 (round 2: 4 x the mean, at least 512).  The accumulate kernel's thread walks a bucket's
+        // first cap entries one after the other -- 6.7 us each when it is the last one running -- so a few buckets of 500
+        // were a 3.4-ms tail; and the factor is 8 because table mode is not uniform: the top window's 2^t digits land
+        // on the first 2^t buckets of the shared set (c = 20: 2.2 x the mean there), which 4 x the mean would already
+        // turn into heavy buckets now and then (measured: +0.3 ms per 2^20 MSM for the extra launch's work)
+        const uint32_t cap = (uint32_t)std::max<uint64_t>(ctx->msm_cap_min, 8 * ((total + nb_used - 1) / nb_used));
+        const uint64_t max_tasks = total / MSM_TASK_LEN_MIN + total / cap + 2;   // sum of ceil(count / task length) over buckets > cap
+        if ((rc = ensure(ctx, sb.heavy, max_tasks * 16))) return rc;
+        if ((rc = ensure(ctx, sb.tasks, max_tasks * 12))) return rc;
         if ((rc = ensure(ctx, sb.hpart, max_tasks * 192))) return rc;
         uint32_t* keys = (uint32_t*)sb.keys.p;
         uint32_t* sorted = (uint32_t*)sb.sorted.p;
@@ -982,7 +988,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             StageTimer st(ctx, "msm_accum", s);
             launch_msm_accum(pts, offsets, sorted, (const uint32_t*)sb.order.p, (uint32_t)nb_used, cap, /*init=*/k > 0, lanes,
                              split, buckets, s);
-            launch_msm_heavy(pts, sorted, (uint32_t*)sb.ohist.p, (const uint32_t*)sb.heavy.p,
+            launch_msm_heavy(pts, sorted, (const uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p,
                              (const uint32_t*)sb.tasks.p, (uint32_t*)sb.hpart.p, buckets, s);
             if (chain) {
                 if (!ctx->accum_chain) HIPCHK(hipEventCreateWithFlags(&ctx->accum_chain, hipEventDisableTiming));
@@ -1413,6 +1419,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_HOST_PLANES")) ctx->msm_host_planes = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_SIDE_PRIO")) ctx->msm_side_prio = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_CHAIN")) ctx->msm_chain = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_MSM_CAP_MIN")) ctx->msm_cap_min = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("TYPLONK_MSM_LANES_SPLIT")) ctx->msm_lanes_split = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
         const int l = atoi(e);

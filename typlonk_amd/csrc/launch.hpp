@@ -14,6 +14,12 @@ constexpr int MSM_SEG = 8;            // buckets per reduce thread
 // accumulate kernel then touches exactly one 128-B line instead of 1.75 on average (PMC FETCH_SIZE
 // of msm_accum_kernel: 3.9 GB -> see profiles/).
 constexpr int PT_WORDS = 32;
+// a heavy bucket of `count` entries (more than `cap`, msm_sort.hip) is cut into tasks of this many entries, one wavefront
+// each: 4 entries per lane before the six butterfly steps, 16 for the very large buckets (where the tasks are many and
+// the butterfly is the cost: 2^20 equal scalars 20 -> 5.4 ms; with a few thousand heavy entries the short tasks win)
+__host__ __device__ inline uint32_t msm_task_len(uint32_t count) { return count >= 65536u ? 1024u : 256u; }
+constexpr uint32_t MSM_TASK_LEN_MIN = 256;
+constexpr int MSM_HEAVY_GRID = 1024;   // workgroups of msm_heavy_kernel (four wavefronts each; grid-strided over the tasks)
 
 // arguments of the quotient pointwise kernel (quotient.hip): every array holds 4n coset evaluations
 struct QuotientArgs {
@@ -98,7 +104,7 @@ TY_HD uint32_t msm_windows(uint32_t c, bool centred) {
 void launch_srs_tables(uint32_t* pts, uint64_t len, uint32_t c, uint32_t T, hipStream_t s);
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
                          uint32_t* order, uint32_t* heavy, uint32_t* tasks, bool hist_done, hipStream_t s);
-void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, uint32_t* hist516, const uint32_t* heavy,
+void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist516, uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s);
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,
                         hipStream_t s);

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_kernel(const uint32
     if (t >= nbuckets) return;
     const uint32_t g = order[t];
     const uint32_t start = offsets[g];
-    const uint32_t end = min(offsets[g + 1], start + cap);  // the tail of a heavy bucket goes to msm_heavy_kernel
+    const uint32_t end = offsets[g + 1] - start > cap ? start : offsets[g + 1];  // a heavy bucket is msm_heavy_kernel's
     // init != 0: a later chunk of the same MSM (capi.hip, msm_enqueue) continues from the stored bucket
     if (init && start >= end) return;
     G1Xyzz acc = init ? ld_xyzz(buckets, g) : G1Xyzz::inf();
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_ml_kernel(const uin
     if (slot < nbuckets) {
         g = order[slot];
         start = offsets[g];
-        end = min(offsets[g + 1], start + cap);
+        end = offsets[g + 1] - start > cap ? start : offsets[g + 1];   // a heavy bucket is msm_heavy_kernel's
     }
     const bool skip = slot >= nbuckets || (init && start >= end);   // nothing to add: the stored bucket stays
     G1Xyzz acc = (init && !skip && lane == 0) ? ld_xyzz(buckets, g) : G1Xyzz::inf();
@@ -110,40 +110,52 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_ml_kernel(const uin
     if (!skip && lane == 0) st_xyzz(buckets, g, acc);
 }
 
-// Heavy buckets (adversarial scalar sets only): tasks one per thread, grid-strided (the task count lives on the
-// device), then the LAST workgroup to finish adds every heavy bucket's task partials into the bucket -- one launch
-// for both steps, and with no task at all (every ordinary MSM) the launch returns at once.
-// hist516: [512] heavy buckets, [513] tasks, [514] workgroups done (left at zero again).
+// Heavy buckets (adversarial scalar sets, or a fixed-base window count whose top window is only a few bits wide): a bucket
+// with more than `cap` entries is skipped by the accumulate kernel and was cut into tasks of msm_task_len(count) entries
+// (msm_seg_sort_kernel / order kernels).  ONE WAVEFRONT per task, grid-strided (the task count lives on the device): the 64
+// lanes stride over the task's entries and a butterfly folds them -- a task is 4 (16) additions and six butterfly steps
+// deep instead of cap additions in a row.  The wavefront that finishes the LAST task of a bucket (a counter per heavy
+// bucket) folds that bucket's partials in the same way and adds them to the bucket: every bucket is closed as soon as it
+// can be, by whichever wavefront gets there, with no second launch and no grid-wide wait.  With no task at all (every
+// ordinary MSM) the launch returns at once.  Round 2 ran a task on ONE thread (cap = 512: a 3.4-ms chain) and folded all
+// buckets in the last workgroup: a 2^20-term MSM of 1024 distinct scalars took 349 ms, a 2^16-term one whose top window
+// holds 2 bits 10 ms (profiles/r03_heavy_tasks_ab.txt).
+// hist516: [512] heavy buckets, [513] tasks.
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_kernel(const uint32_t* __restrict__ points,
-                                                                    const uint32_t* __restrict__ sorted, uint32_t* hist516,
-                                                                    const uint32_t* __restrict__ heavy,
+                                                                    const uint32_t* __restrict__ sorted,
+                                                                    const uint32_t* __restrict__ hist516, uint32_t* heavy,
                                                                     const uint32_t* __restrict__ tasks, uint32_t* partial,
                                                                     uint32_t* buckets) {
-    __shared__ uint32_t is_last;
     const uint32_t ntasks = hist516[513];
     if (ntasks == 0) return;
-    for (uint32_t t = blockIdx.x * MSM_ACC_THREADS + threadIdx.x; t < ntasks; t += gridDim.x * MSM_ACC_THREADS) {
+    constexpr uint32_t WPG = MSM_ACC_THREADS / 64;   // wavefronts per workgroup
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t t = blockIdx.x * WPG + wave; t < ntasks; t += gridDim.x * WPG) {   // t is uniform in the wavefront
         G1Xyzz acc = G1Xyzz::inf();
-        for (uint32_t pos = tasks[2 * t]; pos < tasks[2 * t + 1]; ++pos) {
+        const uint32_t end = tasks[3 * t + 1], h = tasks[3 * t + 2];
+        for (uint32_t pos = tasks[3 * t] + lane; pos < end; pos += 64) {
             const uint32_t pl = sorted[pos];
             g1_madd(acc, unpack_point(ld_packed(points, pl & 0x7fffffffu)), (pl >> 31) != 0);
         }
-        st_xyzz(partial, t, acc);
+#pragma unroll 1
+        for (int mask = 1; mask < 64; mask <<= 1) acc = butterfly_add(acc, mask);
+        const uint32_t k = heavy[4 * h + 2];
+        uint32_t last = 0;
+        if (lane == 0) {
+            st_xyzz(partial, t, acc);
+            __threadfence();   // the partial is visible device-wide before the task counts as done
+            last = atomicAdd(&heavy[4 * h + 3], 1u) == k - 1 ? 1u : 0u;
+        }
+        last = (uint32_t)__shfl((int)last, 0);
+        if (!last) continue;
+        __threadfence();       // ... and whoever closes the bucket sees every task's partial
+        const uint32_t b = heavy[4 * h], t0 = heavy[4 * h + 1];
+        acc = G1Xyzz::inf();
+        for (uint32_t u = lane; u < k; u += 64) acc = g1_add(acc, ld_xyzz(partial, t0 + u));
+#pragma unroll 1
+        for (int mask = 1; mask < 64; mask <<= 1) acc = butterfly_add(acc, mask);
+        if (lane == 0) st_xyzz(buckets, b, g1_add(ld_xyzz(buckets, b), acc));
     }
-    __threadfence();  // this workgroup's partials are visible device-wide before it counts itself done
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(&hist516[514], 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();  // ... and the last one sees everybody's
-    const uint32_t nheavy = hist516[512];
-    for (uint32_t h = threadIdx.x; h < nheavy; h += MSM_ACC_THREADS) {
-        const uint32_t b = heavy[3 * h], t0 = heavy[3 * h + 1], k = heavy[3 * h + 2];
-        G1Xyzz acc = ld_xyzz(buckets, b);
-        for (uint32_t t = 0; t < k; ++t) acc = g1_add(acc, ld_xyzz(partial, t0 + t));
-        st_xyzz(buckets, b, acc);
-    }
-    if (threadIdx.x == 0) hist516[514] = 0;
 }
 
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
@@ -166,9 +178,9 @@ void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uin
         default: hipLaunchKernelGGL(msm_accum_ml_kernel<16>, grid, block, 0, s, points, offsets, sorted, order, nbuckets, cap, in, split, buckets); break;
     }
 }
-void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, uint32_t* hist516, const uint32_t* heavy,
+void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist516, uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s) {
-    hipLaunchKernelGGL(msm_heavy_kernel, dim3(256), dim3(MSM_ACC_THREADS), 0, s, points, sorted, hist516, heavy, tasks, partial,
+    hipLaunchKernelGGL(msm_heavy_kernel, dim3(MSM_HEAVY_GRID), dim3(MSM_ACC_THREADS), 0, s, points, sorted, hist516, heavy, tasks, partial,
                        buckets);
 }
 

@@ -426,19 +426,22 @@ __global__ __launch_bounds__(1024) void msm_seg_sort_kernel(const uint32_t* __re
         counts[bucket] = mine;
         offsets[bucket] = start + excl;
         if (s + 1 == sh.nseg && tid + 1 == nlow) offsets[bucket + 1] = end;
-        if (mine > cap) {  // heavy bucket: the accumulate kernel takes the first cap entries, tasks the rest
-            const uint32_t k = (mine - cap + cap - 1) / cap;
+        if (mine > cap) {  // heavy bucket: the accumulate kernel leaves it alone, tasks of tl entries take all of it
+            const uint32_t tl = msm_task_len(mine);
+            const uint32_t k = (mine + tl - 1) / tl;
             const uint32_t hi = atomicAdd(&ohist[512], 1u);
             const uint32_t t0 = atomicAdd(&ohist[513], k);
-            heavy[3 * hi] = bucket;
-            heavy[3 * hi + 1] = t0;
-            heavy[3 * hi + 2] = k;
-            uint32_t b = start + excl + cap;
+            heavy[4 * hi] = bucket;
+            heavy[4 * hi + 1] = t0;
+            heavy[4 * hi + 2] = k;
+            heavy[4 * hi + 3] = 0;   // tasks done (msm_heavy_kernel: the wavefront that finishes the last one folds the bucket)
+            uint32_t b = start + excl;
             const uint32_t e = start + excl + mine;
             for (uint32_t t = 0; t < k; ++t) {
-                tasks[2 * (t0 + t)] = b;
-                tasks[2 * (t0 + t) + 1] = min(b + cap, e);
-                b += cap;
+                tasks[3 * (t0 + t)] = b;
+                tasks[3 * (t0 + t) + 1] = min(b + tl, e);
+                tasks[3 * (t0 + t) + 2] = hi;
+                b += tl;
             }
         }
     }
@@ -470,11 +473,11 @@ __global__ __launch_bounds__(1024) void msm_seg_sort_kernel(const uint32_t* __re
 // sizes; handing each wave buckets of (nearly) equal size removes that imbalance.  Counting sort on
 // min(count, 255): LDS-privatised histogram per block, one global atomic per (block, bin).
 //
-// Heavy buckets.  A bucket with more than `cap` entries (only adversarial inputs produce them: equal
-// scalars, tiny scalars, ...) would be summed by a single thread; instead the accumulate kernel takes
-// its first `cap` entries and the rest is cut into tasks of <= cap entries that msm_heavy_kernel
-// spreads over the whole chip.  hist[512] = number of heavy buckets, hist[513] = number of tasks;
-// heavy[3h..3h+2] = (bucket, first task, task count); tasks[2t..2t+1] = (begin, end) in `sorted`.
+// Heavy buckets.  A bucket with more than `cap` entries (adversarial inputs produce them -- equal scalars, tiny
+// scalars, ... -- and a table window count whose top window is a few bits wide) would be summed by a single
+// thread; instead the accumulate kernel skips it and ALL its entries are cut into tasks of msm_task_len(count)
+// entries that msm_heavy_kernel spreads over the whole chip, one wavefront per task.  hist[512] = number of heavy buckets, hist[513] = number of tasks;
+// heavy[4h..4h+3] = (bucket, first task, task count, tasks done); tasks[3t..3t+2] = (begin, end in `sorted`, h).
 __global__ __launch_bounds__(256) void order_hist_kernel(const uint32_t* counts, const uint32_t* offsets, uint32_t n,
                                                          uint32_t cap, uint32_t* hist, uint32_t* heavy, uint32_t* tasks) {
     __shared__ uint32_t h[256];
@@ -485,18 +488,21 @@ __global__ __launch_bounds__(256) void order_hist_kernel(const uint32_t* counts,
         const uint32_t cnt = counts[g];
         atomicAdd(&h[min(cnt, 255u)], 1u);
         if (cnt > cap) {
-            const uint32_t k = (cnt - cap + cap - 1) / cap;
+            const uint32_t tl = msm_task_len(cnt);
+            const uint32_t k = (cnt + tl - 1) / tl;
             const uint32_t hi = atomicAdd(&hist[512], 1u);
             const uint32_t t0 = atomicAdd(&hist[513], k);
-            heavy[3 * hi] = g;
-            heavy[3 * hi + 1] = t0;
-            heavy[3 * hi + 2] = k;
-            uint32_t b = offsets[g] + cap;
+            heavy[4 * hi] = g;
+            heavy[4 * hi + 1] = t0;
+            heavy[4 * hi + 2] = k;
+            heavy[4 * hi + 3] = 0;   // tasks done (msm_heavy_kernel: the wavefront that finishes the last one folds the bucket)
+            uint32_t b = offsets[g];
             const uint32_t e = offsets[g] + cnt;
             for (uint32_t t = 0; t < k; ++t) {
-                tasks[2 * (t0 + t)] = b;
-                tasks[2 * (t0 + t) + 1] = min(b + cap, e);
-                b += cap;
+                tasks[3 * (t0 + t)] = b;
+                tasks[3 * (t0 + t) + 1] = min(b + tl, e);
+                tasks[3 * (t0 + t) + 2] = hi;
+                b += tl;
             }
         }
     }
