@@ -18,8 +18,8 @@ python3 tools/msm_timeline.py $(find $O/bench_msm -name "*kernel_trace.csv" | he
 find $O -name "*kernel_trace.csv" -size +4M -delete
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_summary.py $F $W $O/pmc_summary.json > /dev/null
-python3 tools/pmc_sq_summary.py $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_msm.json 2>/dev/null
-python3 tools/pmc_sq_summary.py $(find $O/ntt_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_ntt.json 2>/dev/null
+python3 tools/pmc_sq_summary.py $O/pmc_sq > $O/pmc_sq_msm.json 2>/dev/null
+python3 tools/pmc_sq_summary.py $O/ntt_sq > $O/pmc_sq_ntt.json 2>/dev/null
 F=$(find $O/ntt_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/ntt_write -name "*counter_collection.csv" | head -1)
 python3 - "$F" "$W" <<'PY'
 import csv, sys, collections, json
