@@ -334,6 +334,7 @@ class Circuit {
         c.tables_ = compile_tables<INPUTS, DESC>();
         c.rows = c.tables_.rows;
         c.srs_.reset(new kzg::Srs(kzg::Srs::from_secret(ctx, s, c.rows)));
+        if (c.rows >= ((size_t)1 << 14)) c.srs_->precompute();   // setup-time tables: every commitment of every proof is faster
         std::vector<Fr> sigma[3];
         Fr cosets[3];
         for (int i = 0; i < 3; ++i) {

@@ -251,6 +251,9 @@ class Srs {
         if (id_) typlonk_srs_free(ctx_->raw(), id_);
     }
     size_t len() const { return len_; }
+    // optional, once per SRS: fixed-base tables in HBM (window chosen by the library from the length when 0); every later
+    // commitment over this SRS is faster, results are unchanged -- nothing in the reference corresponds to it
+    void precompute(uint32_t window_bits = 0) const { check(typlonk_srs_precompute(ctx_->raw(), id_, window_bits), ctx_->raw()); }
     std::vector<G1Point> g1_ref() const {  // downloads the points (the reference returns &Vec<G1Point>)
         std::vector<uint64_t> xy(len_ * 12);
         std::vector<uint8_t> inf(len_);
