@@ -582,7 +582,9 @@ def bench_cpu(args, ctx, sh, full, n, log_n, secret, out_xy, out_inf, result) ->
 
         # ... and at the headline size itself (one CPU proof, ~25 s on 128 cores): the measured denominator of the
         # north-star's ">= 10x prove()" -- no extrapolation
-        for lg in sorted({min(16, log_n), log_n}):
+        # (on a small host the full-size CPU proof would take minutes: only with >= 32 cores, or with --cpu-full)
+        full_size_too = (os.cpu_count() or 1) >= 32 or args.cpu_full
+        for lg in sorted({min(16, log_n), log_n} if full_size_too else {min(16, log_n)}):
             chain = SquaringChain(ctx, lg, keep_host=True)
             try:
                 own_srs = lg != log_n or sh.world != 1     # the headline SRS (c = 20 tables) serves the headline size
