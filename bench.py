@@ -130,8 +130,8 @@ class Section:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16,
                     help="terms of the workload timed on the reference-faithful CPU MSM (2^16 ~ 16 s on one host core)")
