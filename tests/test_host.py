@@ -338,3 +338,20 @@ def test_transcript_generator_against_the_crates_published_vectors(built):
         key = (ctypes.c_uint32 * 8)()
         shim.shim_seed_from_u64(ctypes.c_uint64(state), key)
         assert bytes(key) == T.seed_from_u64(state)
+
+
+def test_public_header_is_plain_c99_and_cxx11(tmp_path):
+    """include/typlonk.h is the drop-in boundary a Rust / C / C++ host binds: it must compile on its own
+    as strict C99 and as C++11 -- no HIP, torch or C++-only constructs in the signatures"""
+    import shutil
+    import subprocess
+
+    src = tmp_path / "h.c"
+    src.write_text('#include "typlonk.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cc, args in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++11", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + " not available")
+        r = subprocess.run([cc, *args, "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
