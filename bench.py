@@ -127,6 +127,76 @@ class Section:
         return False
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes of this same script (the
+    environment torch.distributed.run would give them: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT),
+    relay rank 0's contract line as the LAST line of stdout and exit with the ranks' code.  The parent never initialises
+    the GPU (torch.cuda.device_count() does not, on this image) and never exec()s.  With fewer devices than ranks the
+    ranks share devices over gloo (RCCL refuses two ranks per device): the line then says so (`ranks_share_gpu`) --
+    a validation of the sharded path, not a scaling number.  A failing rank still leaves a contract line with "error"."""
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev < n and "TYPLONK_BENCH_BACKEND" not in env:
+        env["TYPLONK_BENCH_BACKEND"] = "gloo"
+    if ndev < n:
+        env["TYPLONK_BENCH_SHARED_GPU"] = f"{n} ranks on {ndev} device(s)"
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    last = [None]
+
+    def relay():
+        for line in procs[0].stdout:
+            if line.startswith('{"metric"'):
+                last[0] = line.rstrip("\n")          # held back: it must be the last line of the parent's stdout
+            else:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    # a rank that dies leaves its peers inside a collective until the process-group timeout: give them a grace period,
+    # then end exactly the processes started here
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.time() + float(os.environ.get("TYPLONK_BENCH_GRACE_S", "30"))
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    th.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    code = next((c for c in codes if c), 0)
+    if last[0] is not None:
+        line = last[0]
+        if code and '"error"' not in line:
+            d = json.loads(line)
+            d["error"] = f"rank exit codes {codes}"
+            line = json.dumps(d)
+        print(line, flush=True)
+    else:
+        print(json.dumps({"metric": "msm_g1_adds_per_s", "value": None, "unit": "G1-adds/s", "n_gpus": n,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                          "error": f"no contract line from rank 0; rank exit codes {codes}"}), flush=True)
+        code = code or 1
+    return code if code > 0 else 1 if code else 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,31 +222,35 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher (it never touches the GPU)
+        sys.exit(self_launch(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        print(json.dumps({"metric": "msm_g1_adds_per_s", "value": None, "unit": "G1-adds/s", "n_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                          "error": f"--gpus {args.gpus} but WORLD_SIZE={world}"}), flush=True)
+        sys.exit(2)
     # TYPLONK_BENCH_BACKEND=gloo lets several ranks share one GPU (validation of the sharded path on a
     # 1-GPU box: RCCL refuses two ranks on the same device); the exchange then goes through host tensors
     backend = os.environ.get("TYPLONK_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1 or os.environ.get("TYPLONK_FORCE_COLLECTIVE") == "1":
-        import datetime
-
-        # a rank that dies must not leave its peers waiting for ever in a collective
-        tmo = datetime.timedelta(seconds=int(os.environ.get("TYPLONK_BENCH_PG_TIMEOUT", "300")))
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device, timeout=tmo)
-        else:
-            dist.init_process_group(backend, timeout=tmo)
-
     result: dict = {"metric": "msm_g1_adds_per_s", "value": None, "unit": "G1-adds/s", "n_gpus": world, "steps": args.steps,
                     "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
                     "vs_baseline": None, "dtype": "u32", "data": "synthetic"}
     state: dict = {"ctx": None}
     code = 0
     try:
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+        if world > 1 or os.environ.get("TYPLONK_FORCE_COLLECTIVE") == "1":
+            import datetime
+
+            # a rank that dies must not leave its peers waiting for ever in a collective
+            tmo = datetime.timedelta(seconds=int(os.environ.get("TYPLONK_BENCH_PG_TIMEOUT", "300")))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device, timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
         run(args, rank, world, backend, dev_index, device, result, state)
     except BaseException as e:  # noqa: BLE001 -- the line below must still be printed
         result["error"] = f"{type(e).__name__}: {e}"
@@ -222,6 +296,13 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
     secret = fr_mont_limbs(2)  # the reference's test secret (kzg/src/lib.rs:97)
     sh = ShardedMsm(ctx, srs_len, rank, world, device if backend == "nccl" else torch.device("cpu"))
     sh.generate_srs(secret)
+    # what the record must show about the exchange: the size of the RCCL communicator the LIBRARY holds (typlonk_comm_info;
+    # 0 = no native communicator: one rank, or the torch.distributed fallback named in `exchange`)
+    result["rccl_world"] = int(ctx.comm_info()[1]) if sh.native else 0
+    result["exchange"] = ("rccl all-gather inside the library" if sh.native else
+                          "none (one rank)" if world == 1 and not sh.force_collective else f"torch.distributed {backend}")
+    if os.environ.get("TYPLONK_BENCH_SHARED_GPU"):
+        result["ranks_share_gpu"] = os.environ["TYPLONK_BENCH_SHARED_GPU"] + ": validation of the sharded path, not a scaling figure"
     # setup, like the SRS upload itself: the SRS is fixed per circuit (plonk/src/lib.rs:22)
     tables_c = None
     if args.tables != "none" and (sh.hi - sh.lo) >= (1 << 16):
@@ -688,6 +769,16 @@ def bench_sharded_prove(ctx, sh, log_n, world, backend, device, result) -> None:
                 proof = run_s()
             sync_all()
             result["prove_sharded_batched_ms"] = (time.perf_counter() - t1) / 3 * 1e3
+            # the reference's proof shape (six openings, 13 MSMs): the figure to hold against the 1-GPU prove_ms
+            run_6 = lambda: sp.prove(chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731
+                                     lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]))
+            run_6()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                run_6()
+            sync_all()
+            result["prove_sharded_ms"] = (time.perf_counter() - t1) / 3 * 1e3
             result["prove_valid"] = bool((proof["evals"][5] == np.zeros(4, dtype=np.uint64)).all())
             if sh.native:   # the one-call native prover on the shard: the library folds every round itself
                 sp.prove_native(chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)

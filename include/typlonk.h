@@ -78,11 +78,14 @@ int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_
 /* Optional fixed-base precomputation (the SRS is immutable per circuit, plonk/src/lib.rs:22): builds the
  * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM -- 15 for c = 17 and 17 for
  * c = 15, which slice centred scalars |k| < 2^254 --, c = window_bits in 14..20, or 0 = chosen by length: 17 below
- * 2^19 points -- an index shard --, else 20, whose top window still has 15 bits).  Later MSMs of at least len/4
+ * 2^19 points -- an index shard --, else 20, whose top window still has 15 bits; with 0 an SRS shorter than
+ * TYPLONK_TABLES_AUTO_MIN_LEN points gets NO tables and the call returns TYPLONK_OK: 2^16 buckets for a handful of
+ * terms would be slower than the plain path).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
  * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point.
  * An MSM length the table-mode sort cannot handle (more than 2^22 terms with 20-bit windows) silently takes the
  * plain path over the same SRS: precomputation never turns a valid MSM into an error. */
+#define TYPLONK_TABLES_AUTO_MIN_LEN 16384
 int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bits);
 /* Multi-GPU: declare that this entry holds bases [first_index, first_index + len) of a total_len-point SRS
  * (one process per GPU, each with its own slice).  Every MSM / prover call on it then takes the FULL
@@ -113,8 +116,13 @@ int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
  * all ranks hash identical points, squeeze identical challenges and return the identical proof.
  * Failure on one rank: the *_sharded_* entry points and typlonk_prove still join the collective of the step that
  * failed, with flagged records, so that rank returns its own error code and every other rank TYPLONK_ERR_COMM
- * (typlonk_last_error names the rank) -- nobody is left waiting; the communicator stays usable. */
+ * (typlonk_last_error names the rank) -- nobody is left waiting; the communicator stays usable.  The exchange buffers
+ * are allocated by typlonk_comm_init; a fold never allocates (more than 32 points go through in pieces).
+ *   typlonk_comm_available   1 if librccl can be loaded in this process (TYPLONK_RCCL_LIB names it, default: the SONAME
+ *                            librccl.so.1), else 0.  NOT collective: ranks agree on it BEFORE the collective
+ *                            typlonk_comm_init, in which a rank that cannot load the library would leave the others waiting. */
 #define TYPLONK_COMM_ID_BYTES 128
+int typlonk_comm_available(void);
 int typlonk_comm_unique_id(uint8_t id[TYPLONK_COMM_ID_BYTES]);
 int typlonk_comm_init(typlonk_ctx* ctx, const uint8_t id[TYPLONK_COMM_ID_BYTES], int rank, int world);
 int typlonk_comm_destroy(typlonk_ctx* ctx);

@@ -41,11 +41,29 @@ def test_two_ranks_sharded_msm_on_one_gpu():
     assert d["msm_batch"]["msms"] == 9 and d["msm_batch"]["first_equals_single"] is True
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as the driver types it (no torch.distributed.run around it): the script starts the two
+    rank processes itself, and the contract line -- n_gpus = 2, the exchange named -- is the LAST line of its stdout."""
+    env = dict(os.environ, TYPLONK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "18", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert out[-1].startswith('{"metric"') and sum(l.startswith('{"metric"') for l in out) == 1
+    d = json.loads(out[-1])
+    assert d["n_gpus"] == 2 and d["value"] is not None and "error" not in d
+    assert d["parity"]["full_commit_identity"] is True
+    assert d["rccl_world"] == 0 and "gloo" in d["exchange"] and "ranks_share_gpu" in d
+    assert d["msm_batch"]["ms_per_msm"] > 0 and d["prove_sharded_ms"] > 0 and d["prove_sharded_batched_ms"] > 0
+
+
 def test_one_rank_through_rccl_all_gather():
     d = _run({"TYPLONK_FORCE_COLLECTIVE": "1"}, 1, ["--gpus", "1", "--steps", "3", "--warmup", "1", "--log-n", "16",
                                                     "--cpu-sample", "2048"])
     assert d["n_gpus"] == 1 and d["parity"]["sample_vs_oracle"] and d["parity"]["full_commit_identity"]
-    assert d["prove_valid"] is True
+    assert d["prove_valid"] is True and d["rccl_world"] == 1 and "rccl" in d["exchange"]
     for key in ("roofline", "cpu_baseline", "ms_per_step", "higher_is_better", "dtype", "data", "config"):
         assert key in d
 

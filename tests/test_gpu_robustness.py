@@ -162,3 +162,28 @@ def test_heavy_bucket_shapes_stay_within_reach_of_the_uniform_case(built):
         assert (a[0] == b[0]).all() and a[1] == b[1]
     finally:
         ctx.close()
+
+
+def test_auto_precompute_leaves_a_short_srs_alone(ctx):
+    """typlonk_srs_precompute(window_bits = 0) on an SRS shorter than TYPLONK_TABLES_AUTO_MIN_LEN points builds nothing
+    (2^16 buckets for a hundred terms would be a cliff) and returns OK; MSMs keep the plain path and the oracle's result,
+    and an explicit window can still be asked for afterwards (it would be refused had tables been built)."""
+    from typlonk_amd.capi import TyplonkError
+
+    n = 100
+    srs = O.srs_from_secret_fast(3, n)
+    from helpers import g1_pack
+
+    xy, inf = g1_pack(srs)
+    sid = ctx.srs_load(xy, inf)
+    ctx.srs_precompute(sid, 0)
+    coeffs = O.random_frs(0xA070, n)
+    out, oinf = ctx.msm(sid, fr_pack(coeffs))
+    assert g1_unpack_one(out, oinf) == O.g1_mul(O.G1, O.poly_eval(coeffs, 3))
+    ctx.srs_precompute(sid, 0)              # still nothing built: not "tables already built"
+    big = ctx.srs_generate(_limbs(3), 1 << 14)
+    ctx.srs_precompute(big, 0)              # at the threshold the tables are built ...
+    with pytest.raises(TyplonkError):
+        ctx.srs_precompute(big, 0)          # ... and a second build is refused
+    ctx.srs_free(sid)
+    ctx.srs_free(big)

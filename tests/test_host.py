@@ -355,3 +355,46 @@ def test_public_header_is_plain_c99_and_cxx11(tmp_path):
         r = subprocess.run([cc, *args, "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_bench_without_a_launcher_still_ends_with_one_contract_line(built):
+    """`python bench.py --gpus 2` with no torch.distributed.run around it starts its own rank processes; without a GPU
+    (this suite) the ranks fail loudly -- no CPU fallback -- and the parent still ends with ONE contract line that
+    carries n_gpus = 2 and the error, and a non-zero exit code."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_dist.py runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "10", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode != 0
+    assert sum(l.startswith('{"metric"') for l in out) == 1 and out[-1].startswith('{"metric"')
+    d = json.loads(out[-1])
+    assert d["n_gpus"] == 2 and d["value"] is None and "No HIP GPUs" in d["error"]
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash(built):
+    """the loader of the RCCL exchange pointed at a library that does not exist (TYPLONK_RCCL_LIB): typlonk_comm_available
+    says 0 and typlonk_comm_unique_id returns TYPLONK_ERR_COMM -- in a fresh process, because the loader resolves once.
+    (Round 3 built the message from two dlerror() calls; the second returns NULL and the string constructor crashed.)"""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes, sys; sys.path.insert(0, %r); import typlonk_amd\n"
+        "lib = typlonk_amd.load_library()\n"
+        "lib.typlonk_comm_available.restype = ctypes.c_int\n"
+        "a = lib.typlonk_comm_available()\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = lib.typlonk_comm_unique_id(buf)\n"
+        "print('RESULT', a, rc)\n" % ROOT)
+    env = dict(os.environ, TYPLONK_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "RESULT 0 -9" in r.stdout, r.stdout + r.stderr[-500:]

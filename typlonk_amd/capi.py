@@ -28,7 +28,7 @@ SYMBOLS = [
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
     "typlonk_version",
-    "typlonk_comm_unique_id", "typlonk_comm_init", "typlonk_comm_destroy", "typlonk_comm_info", "typlonk_comm_fold_g1",
+    "typlonk_comm_available", "typlonk_comm_unique_id", "typlonk_comm_init", "typlonk_comm_destroy", "typlonk_comm_info", "typlonk_comm_fold_g1",
     "typlonk_msm_g1_sharded_devptr", "typlonk_msm_g1_sharded_batch_devptr", "typlonk_g1_fold_records_host",
 ]
 
@@ -113,6 +113,8 @@ def load_library() -> C.CDLL:
     lib.typlonk_msm_g1_devptr.argtypes = [vp, C.c_uint32, vp, C.c_size_t, u64p, u8p]
     lib.typlonk_msm_g1_batch_devptr.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, u64p, u8p]
     lib.typlonk_g1_fold_records_host.argtypes = [u64p, C.c_size_t, C.c_size_t, u64p, u8p, C.POINTER(C.c_int)]
+    lib.typlonk_comm_available.argtypes = []
+    lib.typlonk_comm_available.restype = C.c_int
     lib.typlonk_comm_unique_id.argtypes = [u8p]
     lib.typlonk_comm_init.argtypes = [vp, u8p, C.c_int, C.c_int]
     lib.typlonk_comm_destroy.argtypes = [vp]
@@ -170,6 +172,11 @@ def _u8p(a: np.ndarray):
 def _as_u64(a, cols: int) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return a.reshape(-1, cols)
+
+
+def comm_available() -> bool:
+    """typlonk_comm_available: can librccl be loaded in this process?  Not collective -- ranks agree on it before comm_init"""
+    return bool(load_library().typlonk_comm_available())
 
 
 def comm_unique_id() -> bytes:

@@ -121,12 +121,19 @@ struct RcclApi {
 RcclApi* rccl_api() {
     static RcclApi api;
     if (api.handle || !api.err.empty()) return &api;
+    // TYPLONK_RCCL_LIB names the library to load (a deployment with its own RCCL build); otherwise the SONAME, which a
+    // process that already holds a copy resolves to that copy
+    const char* forced = getenv("TYPLONK_RCCL_LIB");
+    std::string why = "not found";
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (forced && *forced) name = forced;
         api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (api.handle) break;
+        if (const char* e = dlerror()) why = e;   // ONE call: dlerror() clears the message it returns
+        if (forced && *forced) break;
     }
     if (!api.handle) {
-        api.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+        api.err = "cannot load librccl: " + why;
         return &api;
     }
     auto sym = [&](const char* n) -> void* {
@@ -1250,19 +1257,16 @@ void comm_release(typlonk_ctx* ctx) {
     c = Comm{};
 }
 
-int comm_reserve(typlonk_ctx* ctx, size_t count) {
+// The exchange buffers are allocated ONCE, by typlonk_comm_init (COMM_CAP records: more than the 9 points of a prover
+// round): a fold never allocates, so no rank can fail locally between "decided to fold" and the collective and leave
+// its peers waiting.  Longer point lists go through in pieces of COMM_CAP records (comm_fold).
+constexpr size_t COMM_CAP = 32;
+int comm_reserve(typlonk_ctx* ctx) {
     Comm& c = ctx->comm;
-    if (c.cap >= count) return TYPLONK_OK;
-    const size_t cap = std::max<size_t>(16, count);
-    if (c.d_send) HIPCHK(hipFree(c.d_send));
-    if (c.d_recv) HIPCHK(hipFree(c.d_recv));
-    if (c.h_buf) HIPCHK(hipHostFree(c.h_buf));
-    c.d_send = c.d_recv = c.h_buf = nullptr;
-    c.cap = 0;
-    HIPCHK(hipMalloc((void**)&c.d_send, cap * COMM_REC * 8));
-    HIPCHK(hipMalloc((void**)&c.d_recv, (size_t)c.world * cap * COMM_REC * 8));
-    HIPCHK(hipHostMalloc((void**)&c.h_buf, (size_t)(c.world + 1) * cap * COMM_REC * 8));
-    c.cap = cap;
+    HIPCHK(hipMalloc((void**)&c.d_send, COMM_CAP * COMM_REC * 8));
+    HIPCHK(hipMalloc((void**)&c.d_recv, (size_t)c.world * COMM_CAP * COMM_REC * 8));
+    HIPCHK(hipHostMalloc((void**)&c.h_buf, (size_t)(c.world + 1) * COMM_CAP * COMM_REC * 8));
+    c.cap = COMM_CAP;
     return TYPLONK_OK;
 }
 
@@ -1276,9 +1280,16 @@ int comm_fold(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count, int lo
     Comm& c = ctx->comm;
     if (!c.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
     if (!count) return local_rc;
+    if (count > c.cap) {   // pieces of COMM_CAP records, each its own collective: the same sequence on every rank
+        int rc = TYPLONK_OK;
+        for (size_t i = 0; i < count; i += c.cap) {
+            const int r = comm_fold(ctx, xy + 12 * i, inf + i, std::min(c.cap, count - i), local_rc);
+            if (!rc) rc = r;
+        }
+        return rc;
+    }
     const std::string local_err = local_rc ? ctx->err : std::string();
-    int rc = comm_reserve(ctx, count);
-    if (rc) return rc;
+    int rc = TYPLONK_OK;
     uint64_t* out = c.h_buf;
     uint64_t* back = c.h_buf + c.cap * COMM_REC;
     for (size_t i = 0; i < count; ++i) {
@@ -1343,8 +1354,16 @@ int typlonk_comm_init(typlonk_ctx* ctx, const uint8_t id[TYPLONK_COMM_ID_BYTES],
     ctx->comm.comm = comm;
     ctx->comm.rank = rank;
     ctx->comm.world = world;
+    const int rc = comm_reserve(ctx);   // every rank allocates here, before any fold: a failure is reported by this call
+    if (rc) {
+        const std::string msg = ctx->err;
+        comm_release(ctx);
+        return fail(ctx, rc, msg);
+    }
     return TYPLONK_OK;
 }
+
+int typlonk_comm_available(void) { return rccl_api()->err.empty() ? 1 : 0; }
 
 int typlonk_comm_destroy(typlonk_ctx* ctx) {
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
@@ -1574,7 +1593,13 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     auto it = ctx->srs.find(srs_id);
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
-    if (window_bits == 0) window_bits = it->second.len < (1u << 19) ? 17 : 20;   // measured best: DESIGN.md section 6
+    if (window_bits == 0) {
+        // auto: 17 below 2^19 points, else 20 (measured best: DESIGN.md section 6) -- and nothing at all for an SRS shorter
+        // than 2^14 points: 2^16 buckets (sort, reduction, heavy-bucket launch) for a handful of terms would be slower
+        // than the plain path, whose window follows the length
+        if (it->second.len < TYPLONK_TABLES_AUTO_MIN_LEN) return TYPLONK_OK;
+        window_bits = it->second.len < (1u << 19) ? 17 : 20;
+    }
     if (window_bits < 14 || window_bits > 20) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "window_bits must be 0 (auto) or 14..20");
     SrsEntry& e = it->second;
     if (e.table_T) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "tables already built for this SRS");

@@ -82,7 +82,7 @@ class ShardedMsm:
         self.native = False
         if dist.is_initialized() and dist.get_backend(group) == "nccl" and (world > 1 or self.force_collective) \
                 and os.environ.get("TYPLONK_NATIVE_COMM", "1") != "0":
-            from .capi import comm_unique_id
+            from .capi import comm_available, comm_unique_id
             # A rank on which the native communicator cannot come up must not leave the others inside a collective of
             # a communicator it is not part of: every step is agreed on by all ranks (MIN over a flag), and if any rank
             # failed, all of them fall back to the torch.distributed exchange below.
@@ -92,10 +92,14 @@ class ShardedMsm:
                 return bool(t.item())
 
             box, err = [None], None
+            # comm_init is itself a collective (ncclCommInitRank): every rank first confirms -- without entering one --
+            # that it can load librccl at all (typlonk_comm_available), so that no rank waits inside comm_init alone
+            if not comm_available():
+                err = RuntimeError("librccl cannot be loaded on this rank")
             try:
-                if rank == 0:
+                if rank == 0 and err is None:
                     box[0] = comm_unique_id()
-            except Exception as e:  # noqa: BLE001 -- librccl missing: reported, not fatal
+            except Exception as e:  # noqa: BLE001 -- reported, not fatal
                 err = e
             if agree(err is None):
                 dist.broadcast_object_list(box, src=0, group=group, device=device)
