@@ -1,0 +1,278 @@
+//! Rust side of `libtyplonk_hip.so` -- the safe layer a TyPLONK maintainer calls from the `kzg` and `plonk` crates.
+//!
+//! SOURCE ONLY: this repository's image has no Rust toolchain, so nothing in this crate has been through `rustc`.
+//! What IS tested is the C side every function here forwards to (`include/typlonk.h`, exercised through ctypes and
+//! through the C++ mirror `typlonk_amd/host/typlonk_host.hpp`, which has the same shape as this file).
+//!
+//! Seams (file:line under the reference):
+//!   * `Backend::msm`            replaces the body of `KzgScheme::evaluate_in_s`      kzg/src/lib.rs:41-54
+//!   * `Backend::upload_srs`     once per `Srs` (`Srs::from_secret`)                  kzg/src/srs.rs:30-34
+//!   * `Backend::interpolate` / `evaluate_over_domain`
+//!                               replace `Evaluations::interpolate()` / `evaluate_over_domain()`
+//!                               plonk/src/proof.rs:50,106,115,125,128  plonk/src/builder.rs:85
+//!   * `Backend::load_circuit` + `Backend::prove`
+//!                               replace the body of `plonk::proof::prove`           plonk/src/proof.rs:96-194
+//!
+//! Data crosses the boundary in arkworks' own in-memory form (`Fp256.0 .0`: 4 LE u64 limbs of the Montgomery residue;
+//! `Fp384.0 .0`: 6), so nothing is converted -- coordinates are copied limb-wise because `GroupAffine` is `repr(Rust)`.
+pub mod ffi;
+
+use ark_bls12_381::{Fq, Fr, G1Affine};
+use ark_ff::{BigInteger256, BigInteger384, Zero};
+use ark_poly::{univariate::DensePolynomial, UVPolynomial};
+use std::ffi::CStr;
+use std::os::raw::c_int;
+use std::ptr;
+
+pub type G1Point = G1Affine;
+pub type Poly = DensePolynomial<Fr>;
+
+/// One HIP device + stream + workspaces (`typlonk_ctx`).  Not `Sync`: one host thread per context (typlonk.h).
+pub struct Backend {
+    ctx: *mut ffi::TyplonkCtx,
+}
+
+/// An SRS resident in HBM (`typlonk_srs_load`), with the fixed-base tables the library chooses for its length.
+#[derive(Debug, Clone, Copy)]
+pub struct SrsHandle {
+    pub id: u32,
+    pub len: usize,
+}
+
+/// Per-circuit constants of the quotient on the device (`typlonk_circuit_load`): selectors and sigmas on the 4n coset.
+#[derive(Debug, Clone, Copy)]
+pub struct CircuitHandle {
+    pub id: u32,
+    pub log_n: u32,
+}
+
+/// A device-resident vector of Fr (`typlonk_buf`), freed on drop.
+pub struct DeviceVec<'a> {
+    backend: &'a Backend,
+    buf: *mut ffi::TyplonkBuf,
+}
+
+impl std::fmt::Debug for Backend {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "typlonk::Backend({:p})", self.ctx)
+    }
+}
+
+fn fr_limbs(x: &Fr) -> [u64; 4] {
+    (x.0).0
+}
+fn fr_from_limbs(l: [u64; 4]) -> Fr {
+    // the limbs ARE the Montgomery residue: construct without a conversion (ark-ff 0.3: `Fp256::new(BigInteger256)`)
+    Fr::new(BigInteger256(l))
+}
+fn g1_from_abi(xy: &[u64; 12], inf: u8) -> G1Point {
+    let mut x = [0u64; 6];
+    let mut y = [0u64; 6];
+    x.copy_from_slice(&xy[0..6]);
+    y.copy_from_slice(&xy[6..12]);
+    // identity comes back as (0, 1, inf = 1) = GroupAffine::zero()
+    G1Point::new(Fq::new(BigInteger384(x)), Fq::new(BigInteger384(y)), inf != 0)
+}
+
+impl Backend {
+    /// `typlonk_init`: fails (panics, like the reference's `unwrap()`s) when there is no HIP device -- no CPU fallback.
+    pub fn new(device_ordinal: i32) -> Self {
+        let mut ctx = ptr::null_mut();
+        let rc = unsafe { ffi::typlonk_init(&mut ctx, device_ordinal as c_int) };
+        if rc != ffi::TYPLONK_OK {
+            panic!("typlonk_init: {}", strerror(rc));
+        }
+        Backend { ctx }
+    }
+
+    /// negative code -> panic with the library's message: the reference panics at the same places
+    /// (`TYPLONK_ERR_LENGTH` <=> `assert!(srs.len() > polynomial.degree())`, kzg/src/lib.rs:43)
+    fn check(&self, rc: c_int) {
+        if rc != ffi::TYPLONK_OK {
+            let detail = unsafe { CStr::from_ptr(ffi::typlonk_last_error(self.ctx)) }.to_string_lossy().into_owned();
+            panic!("{}: {}", strerror(rc), detail);
+        }
+    }
+
+    // ---- SRS ------------------------------------------------------------------------------------------------------
+    /// once per `Srs` (kzg/src/srs.rs:30-34): copy the G1 powers to HBM and let the library build its tables
+    pub fn upload_srs(&self, g1: &[G1Point]) -> SrsHandle {
+        let mut xy = Vec::with_capacity(g1.len() * 12);
+        let mut inf = Vec::with_capacity(g1.len());
+        for p in g1 {
+            xy.extend_from_slice(&(p.x.0).0);
+            xy.extend_from_slice(&(p.y.0).0);
+            inf.push(p.infinity as u8);
+        }
+        let mut id = 0u32;
+        self.check(unsafe { ffi::typlonk_srs_load(self.ctx, xy.as_ptr(), inf.as_ptr(), g1.len(), &mut id) });
+        // speed only, results unchanged; 0 = window chosen by length (nothing below TYPLONK_TABLES_AUTO_MIN_LEN points)
+        self.check(unsafe { ffi::typlonk_srs_precompute(self.ctx, id, 0) });
+        SrsHandle { id, len: g1.len() }
+    }
+
+    /// `Srs::from_secret` on the device: `[s^(start + i)] G`, i < len (each GPU of a node builds only its shard)
+    pub fn generate_srs(&self, secret: &Fr, start: u64, len: usize) -> SrsHandle {
+        let s = fr_limbs(secret);
+        let mut id = 0u32;
+        self.check(unsafe { ffi::typlonk_srs_generate(self.ctx, s.as_ptr(), start, len, &mut id) });
+        self.check(unsafe { ffi::typlonk_srs_precompute(self.ctx, id, 0) });
+        SrsHandle { id, len }
+    }
+
+    // ---- MSM seam: the body of KzgScheme::evaluate_in_s (kzg/src/lib.rs:41-54) -------------------------------------
+    /// sum_i coeffs[i] * srs[i].  `coeffs` are the polynomial's coefficients with ark-poly's trailing-zero trim, so the
+    /// MSM length is what the reference's `zip` would have consumed.
+    pub fn msm(&self, srs: SrsHandle, coeffs: &[Fr]) -> G1Point {
+        let mut scalars = Vec::with_capacity(coeffs.len() * 4);
+        for c in coeffs {
+            scalars.extend_from_slice(&fr_limbs(c));
+        }
+        let (mut xy, mut inf) = ([0u64; 12], 0u8);
+        self.check(unsafe {
+            ffi::typlonk_msm_g1(self.ctx, srs.id, scalars.as_ptr(), coeffs.len(), xy.as_mut_ptr(), &mut inf)
+        });
+        g1_from_abi(&xy, inf)
+    }
+
+    /// the same with the coefficients already in HBM (an iNTT result feeding a commitment: proof.rs:50 -> :109)
+    pub fn msm_dev(&self, srs: SrsHandle, v: &DeviceVec, offset: usize, m: usize) -> G1Point {
+        let (mut xy, mut inf) = ([0u64; 12], 0u8);
+        self.check(unsafe { ffi::typlonk_msm_g1_dev(self.ctx, srs.id, v.buf, offset, m, xy.as_mut_ptr(), &mut inf) });
+        g1_from_abi(&xy, inf)
+    }
+
+    // ---- NTT seam ---------------------------------------------------------------------------------------------------
+    /// `Evaluations::from_vec_and_domain(evals, domain).interpolate()`: ifft, then ark-poly's trailing-zero trim
+    /// (`from_coefficients_vec`), which is what sets MSM lengths downstream
+    pub fn interpolate(&self, mut evals: Vec<Fr>, log_n: u32) -> Poly {
+        assert_eq!(evals.len(), 1usize << log_n);
+        let mut limbs: Vec<u64> = evals.iter().flat_map(|e| fr_limbs(e)).collect();
+        self.check(unsafe { ffi::typlonk_ntt_fr(self.ctx, limbs.as_mut_ptr(), log_n, 1, ptr::null()) });
+        for (e, l) in evals.iter_mut().zip(limbs.chunks_exact(4)) {
+            *e = fr_from_limbs([l[0], l[1], l[2], l[3]]);
+        }
+        Poly::from_coefficients_vec(evals)
+    }
+
+    /// `poly.evaluate_over_domain(domain).evals`: zero-pad to the domain size, fft, natural order
+    pub fn evaluate_over_domain(&self, poly: &Poly, log_n: u32) -> Vec<Fr> {
+        let n = 1usize << log_n;
+        assert!(poly.coeffs.len() <= n);
+        let mut limbs = vec![0u64; 4 * n];
+        for (c, l) in poly.coeffs.iter().zip(limbs.chunks_exact_mut(4)) {
+            l.copy_from_slice(&fr_limbs(c));
+        }
+        self.check(unsafe { ffi::typlonk_ntt_fr(self.ctx, limbs.as_mut_ptr(), log_n, 0, ptr::null()) });
+        limbs.chunks_exact(4).map(|l| fr_from_limbs([l[0], l[1], l[2], l[3]])).collect()
+    }
+
+    // ---- device vectors ---------------------------------------------------------------------------------------------
+    pub fn upload(&self, v: &[Fr], capacity: usize) -> DeviceVec<'_> {
+        let mut buf = ptr::null_mut();
+        self.check(unsafe { ffi::typlonk_buf_alloc(self.ctx, capacity.max(v.len()), &mut buf) });
+        let d = DeviceVec { backend: self, buf };
+        self.check(unsafe { ffi::typlonk_buf_zero(self.ctx, buf, 0, capacity.max(v.len())) });
+        let limbs: Vec<u64> = v.iter().flat_map(|e| fr_limbs(e)).collect();
+        self.check(unsafe { ffi::typlonk_buf_upload(self.ctx, buf, 0, limbs.as_ptr(), v.len()) });
+        d
+    }
+
+    // ---- whole prover ---------------------------------------------------------------------------------------------
+    /// once per `CompiledCircuit` (plonk/src/lib.rs:19-35): the five selector polynomials (coefficients, zero-padded
+    /// to n) and the three sigma polynomials (`interpolate` of `copy_constrains.cols[i]`'s second components)
+    pub fn load_circuit(&self, selectors: [&Poly; 5], sigma: [&Poly; 3], log_n: u32) -> CircuitHandle {
+        let n = 1usize << log_n;
+        let sel: Vec<DeviceVec> = selectors.iter().map(|p| self.upload(&p.coeffs, n)).collect();
+        let sig: Vec<DeviceVec> = sigma.iter().map(|p| self.upload(&p.coeffs, n)).collect();
+        let selp: Vec<*const ffi::TyplonkBuf> = sel.iter().map(|d| d.buf as *const _).collect();
+        let sigp: Vec<*const ffi::TyplonkBuf> = sig.iter().map(|d| d.buf as *const _).collect();
+        let mut id = 0u32;
+        self.check(unsafe { ffi::typlonk_circuit_load(self.ctx, selp.as_ptr(), sigp.as_ptr(), log_n, &mut id) });
+        CircuitHandle { id, log_n }
+    }
+
+    /// `plonk::proof::prove` (plonk/src/proof.rs:96-194) in one native call: `wire_evals` are the three padded and
+    /// blinded witness COLUMNS (what `CompiledCircuit::prove` builds at :43-49, before `.interpolate()`),
+    /// `public_inputs` the padded public-input column (:52-53), `cosets` = `copy_constrains.cosets`.
+    /// Panics with "r(zeta) != 0" where the reference panics in `vanishes()` (:321, :361).
+    pub fn prove(&self, srs: SrsHandle, circuit: CircuitHandle, wire_evals: [&[Fr]; 3], public_inputs: &[Fr],
+                 cosets: [Fr; 3]) -> ffi::TyplonkProof {
+        let n = 1usize << circuit.log_n;
+        let w: Vec<DeviceVec> = wire_evals.iter().map(|c| self.upload(c, n)).collect();
+        let wp: Vec<*const ffi::TyplonkBuf> = w.iter().map(|d| d.buf as *const _).collect();
+        let pi = if public_inputs.iter().all(|x| x.is_zero()) { None } else { Some(self.upload(public_inputs, n)) };
+        let k = [fr_limbs(&cosets[0]), fr_limbs(&cosets[1]), fr_limbs(&cosets[2])];
+        let mut out = std::mem::MaybeUninit::<ffi::TyplonkProof>::zeroed();
+        self.check(unsafe {
+            ffi::typlonk_prove(self.ctx, srs.id, circuit.id, wp.as_ptr(),
+                               pi.as_ref().map_or(ptr::null(), |d| d.buf as *const _), k.as_ptr(), out.as_mut_ptr())
+        });
+        unsafe { out.assume_init() }
+    }
+
+    // ---- multi-GPU: one process per GPU, RCCL inside the library --------------------------------------------------
+    /// this process holds bases [first, first + len) of a `total`-point SRS
+    pub fn set_shard(&self, srs: SrsHandle, first: usize, total: usize) {
+        self.check(unsafe { ffi::typlonk_srs_set_shard(self.ctx, srs.id, first, total) });
+    }
+    /// rank 0: the 128-byte rendezvous id, to be handed to the other ranks by any channel the host program has
+    pub fn comm_unique_id() -> [u8; ffi::TYPLONK_COMM_ID_BYTES] {
+        let mut id = [0u8; ffi::TYPLONK_COMM_ID_BYTES];
+        let rc = unsafe { ffi::typlonk_comm_unique_id(id.as_mut_ptr()) };
+        if rc != ffi::TYPLONK_OK {
+            panic!("typlonk_comm_unique_id: {}", strerror(rc));
+        }
+        id
+    }
+    /// every rank (collective).  Call `typlonk_comm_available()` on every rank first and agree on the answer.
+    pub fn comm_init(&self, id: &[u8; ffi::TYPLONK_COMM_ID_BYTES], rank: i32, world: i32) {
+        self.check(unsafe { ffi::typlonk_comm_init(self.ctx, id.as_ptr(), rank, world) });
+    }
+    /// `evaluate_in_s` over the whole node: every rank passes the device address of coefficient 0 of the full vector
+    /// and gets the FULL sum (local partial MSM + one all-gather + fold in rank order)
+    pub fn msm_sharded(&self, srs: SrsHandle, v: &DeviceVec, m: usize) -> G1Point {
+        let (mut xy, mut inf) = ([0u64; 12], 0u8);
+        let p = unsafe { ffi::typlonk_buf_devptr(v.buf) };
+        self.check(unsafe { ffi::typlonk_msm_g1_sharded_devptr(self.ctx, srs.id, p, m, xy.as_mut_ptr(), &mut inf) });
+        g1_from_abi(&xy, inf)
+    }
+}
+
+/// `typlonk_proof` -> the pieces of the reference's `Proof` (plonk/src/proof.rs:65-95)
+pub struct ProofParts {
+    pub commitments: [G1Point; 3],          // [a], [b], [c]
+    pub z_commitment: G1Point,               // permutation.commitment
+    pub t: [G1Point; 3],                     // quotient slices
+    pub witnesses: [G1Point; 6],             // a, b, c at zeta; Z at zeta; Z at zeta*w; r at zeta
+    pub evals: [Fr; 6],                      // a(zeta) b(zeta) c(zeta) Z(zeta) Z(zeta w) r(zeta)
+    pub evaluation_point: Fr,
+}
+impl From<&ffi::TyplonkProof> for ProofParts {
+    fn from(p: &ffi::TyplonkProof) -> Self {
+        let g = |xy: &[u64; 12], inf: u8| g1_from_abi(xy, inf);
+        ProofParts {
+            commitments: [0, 1, 2].map(|i| g(&p.commit_xy[i], p.commit_inf[i])),
+            z_commitment: g(&p.z_xy, p.z_inf),
+            t: [0, 1, 2].map(|i| g(&p.tail.t_xy[i], p.tail.t_inf[i])),
+            witnesses: [0, 1, 2, 3, 4, 5].map(|i| g(&p.tail.w_xy[i], p.tail.w_inf[i])),
+            evals: [0, 1, 2, 3, 4, 5].map(|i| fr_from_limbs(p.tail.evals[i])),
+            evaluation_point: fr_from_limbs(p.zeta),
+        }
+    }
+}
+
+impl Drop for Backend {
+    fn drop(&mut self) {
+        unsafe { ffi::typlonk_destroy(self.ctx) }
+    }
+}
+impl Drop for DeviceVec<'_> {
+    fn drop(&mut self) {
+        unsafe { ffi::typlonk_buf_free(self.backend.ctx, self.buf) };
+    }
+}
+
+fn strerror(rc: c_int) -> String {
+    unsafe { CStr::from_ptr(ffi::typlonk_strerror(rc)) }.to_string_lossy().into_owned()
+}

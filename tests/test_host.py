@@ -398,3 +398,41 @@ def test_missing_librccl_is_an_error_code_not_a_crash(built):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1500:]
     assert "RESULT 0 -9" in r.stdout, r.stdout + r.stderr[-500:]
+
+
+def test_rust_ffi_mirror_is_generated_from_the_header_and_complete(built):
+    """integration/rust/kzg_hip/src/ffi.rs is what tools/gen_rust_ffi.py makes of include/typlonk.h (not stale), and every
+    symbol the library exports appears in it as a `pub fn` -- the Rust side binds the whole boundary, not a sample."""
+    import subprocess
+    import sys
+
+    from typlonk_amd.capi import SYMBOLS
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ffi = open(os.path.join(ROOT, "integration", "rust", "kzg_hip", "src", "ffi.rs")).read()
+    bound = set(re.findall(r"pub fn (typlonk_[a-z0-9_]+)\(", ffi))
+    assert bound == set(SYMBOLS), bound ^ set(SYMBOLS)
+    # the structs that cross the boundary by value keep the header's field order
+    assert re.search(r"pub struct TyplonkProof \{\s*pub commit_xy: \[\[u64; 12\]; 3\],\s*pub commit_inf: \[u8; 3\],\s*pub z_xy", ffi)
+    # and the safe layer only calls functions the mirror declares
+    lib_rs = open(os.path.join(ROOT, "integration", "rust", "kzg_hip", "src", "lib.rs")).read()
+    assert set(re.findall(r"ffi::(typlonk_[a-z0-9_]+)\(", lib_rs)) <= bound
+
+
+def test_rust_patches_apply_to_the_reference(tmp_path):
+    """the two patches under integration/rust/patches apply cleanly (`git apply --check`) to a copy of the reference's
+    kzg / plonk crates -- where the reference tree exists (the development container; not on the GPU box)"""
+    import shutil
+    import subprocess
+
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "kzg")):
+        pytest.skip("no reference tree here")
+    for crate in ("kzg", "plonk"):
+        shutil.copytree(os.path.join(ref, crate), tmp_path / crate)
+    subprocess.run(["git", "init", "-q", "."], cwd=tmp_path, check=True)
+    for p in ("0001-kzg-msm-on-hip.patch", "0002-plonk-prove-on-hip.patch"):
+        r = subprocess.run(["git", "apply", "--check", os.path.join(ROOT, "integration", "rust", "patches", p)],
+                           cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, p + ": " + r.stderr
