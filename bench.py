@@ -385,7 +385,7 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
             result["msm_batch_error"] = f"{type(e).__name__}: {e}"
 
     # ---- roofline of the dominant kernel (bucket accumulation), HIP events on the launch stream ----
-    # A stand-alone MSM of >= 2^20 terms launches the accumulation once per chunk of ~2^19 terms (capi.hip, msm_enqueue):
+    # A stand-alone MSM of >= 2^20 terms launches the accumulation once per chunk of ~2^19 terms (msm_host.hip, msm_enqueue):
     # everything below is PER LAUNCH, as rocprofv3's per-kernel average is (profiles/r0x_kernel_stats_bench_msm_only.csv).
     launches = max(1, accum_launches // max(1, args.steps))
     t_acc = stage_ms.get("msm_accum", 0.0) * 1e-3 / launches
@@ -454,7 +454,7 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
         ctx.ntt_devptr(v.data_ptr(), log_n)
     torch.cuda.synchronize()
     # forward and inverse transforms alternate (a round trip leaves the data unchanged); they run on different kernels
-    # from 2^20 up (capi.hip ntt_run: forward on 8 x 32-bit words, inverse on 9 x 30-bit limbs), so both are reported
+    # from 2^20 up (ntt_host.hip ntt_run: forward on 8 x 32-bit words, inverse on 9 x 30-bit limbs), so both are reported
     reps, kdir = 10, [0.0, 0.0]
     t1 = time.perf_counter()
     for i in range(reps):

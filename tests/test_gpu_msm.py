@@ -460,7 +460,7 @@ def test_shard_argument_errors(ctx):
 @pytest.mark.parametrize("chunks", [1, 2, 3, 5, 8])
 def test_chunked_pipeline_gives_identical_results(built, chunks, monkeypatch):
     """A stand-alone MSM is cut into chunks of terms that add into the same buckets (sort of chunk k + 1 overlapping
-    the accumulation of chunk k, capi.hip msm_enqueue).  Every chunk count -- forced through TYPLONK_MSM_CHUNKS --
+    the accumulation of chunk k, msm_host.hip msm_enqueue).  Every chunk count -- forced through TYPLONK_MSM_CHUNKS --
     gives the bit-identical point, with and without fixed-base tables, for uniform and adversarial scalars (heavy
     buckets cross chunk boundaries), full and ragged lengths, and on an SRS shard."""
     import typlonk_amd

@@ -4,7 +4,7 @@
 // re-cut into 9 x 30-bit limbs and every multiplication is a Montgomery multiplication with R' = 2^270:
 //     fr30_mul(a, b) = a * b / 2^270 mod r.
 // The data are never converted: with a twiddle stored as w * 2^270 mod r the product of a datum d = x * 2^256 is
-// d * w, still in arkworks' domain -- only the twiddle tables live in the 2^270 domain (capi.hip builds them with an
+// d * w, still in arkworks' domain -- only the twiddle tables live in the 2^270 domain (ntt_host.hip builds them with an
 // extra factor 2^14).
 //
 // Why it pays (tools/ubench3, profiles/r02_ubench3_fr30.txt): a column of 9 products of 30-bit limbs plus 9 reduction

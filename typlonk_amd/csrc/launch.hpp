@@ -9,7 +9,6 @@
 namespace ty {
 
 constexpr int SCAN_PER_BLOCK = 2048;  // 256 threads x 8
-constexpr int MSM_SEG = 8;            // buckets per reduce thread
 // Resident SRS points are 96 B of payload (x || y packed) on a 128-B stride: every gather of the
 // accumulate kernel then touches exactly one 128-B line instead of 1.75 on average (PMC FETCH_SIZE
 // of msm_accum_kernel: 3.9 GB -> see profiles/).
@@ -113,9 +112,6 @@ void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32
 void launch_msm_accum(const uint32_t* points, const uint32_t* offsets, const uint32_t* sorted, const uint32_t* order,
                       uint32_t nbuckets, uint32_t cap, bool init, uint32_t lanes, uint32_t split, uint32_t* buckets,
                       hipStream_t s);
-void launch_msm_reduce(const uint32_t* buckets, uint32_t B, uint32_t L, uint32_t nodes_total, uint32_t group,
-                       uint32_t cbits, uint32_t W, uint32_t top_v, uint32_t* partials, hipStream_t s);
-void launch_msm_fold(const uint32_t* in, uint32_t total, uint32_t group, uint32_t* out, hipStream_t s);
 
 // Row/column bucket reduction (msm_reduce.hip).  A bucket set of B = 2^c1 buckets is read as a grid of
 // R = 2^ch rows x C = 2^cl columns, k = hi * C + lo.  Every bucket weight splits as w(k) = wr(hi) + wc(lo):

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_kernel(const uint32
     const uint32_t g = order[t];
     const uint32_t start = offsets[g];
     const uint32_t end = offsets[g + 1] - start > cap ? start : offsets[g + 1];  // a heavy bucket is msm_heavy_kernel's
-    // init != 0: a later chunk of the same MSM (capi.hip, msm_enqueue) continues from the stored bucket
+    // init != 0: a later chunk of the same MSM (msm_host.hip, msm_enqueue) continues from the stored bucket
     if (init && start >= end) return;
     G1Xyzz acc = init ? ld_xyzz(buckets, g) : G1Xyzz::inf();
     uint32_t pl_next = 0;

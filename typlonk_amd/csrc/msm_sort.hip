@@ -1,8 +1,5 @@
 // MSM staging kernels: infinity marking, scalar -> signed window digits + histogram, exclusive scan,
 // counting-sort scatter.  See msm_common.hpp for the overall MSM structure.
-#include <stdlib.h>
-#include <string.h>
-
 #include "launch.hpp"
 #include "msm_common.hpp"
 
@@ -165,27 +162,12 @@ __global__ __launch_bounds__(256) void scan_finish_kernel(const uint32_t* in, ui
 // Level-1 entry: idx (23 bits) | sign << 23 | (b & (2^lb - 1)) << 24     (m <= 2^23)
 // scalars per workgroup: 2048 (8 per thread) up to 2^20 terms, growing with m beyond that so the
 // workgroup x segment matrix (nblk * nseg counters) stays bounded instead of growing like m^2
-// threads per workgroup of the level-1 passes (TYPLONK_SEG1_THREADS = 256 | 512 | 1024 for measurements): a bigger
-// workgroup owns a longer chunk, so its run inside each segment is longer and the scattered 4-byte stores of
-// msm_seg_scatter_kernel fill more of every 128-byte line
-inline uint32_t msm_seg1_threads() {
-    static const uint32_t t = [] {
-        const char* e = getenv("TYPLONK_SEG1_THREADS");
-        const int v = e ? atoi(e) : 256;
-        return (uint32_t)((v == 512 || v == 1024) ? v : 256);
-    }();
-    return t;
-}
+// threads per workgroup of the level-1 passes (512 and 1024 were measured: no gain)
+inline uint32_t msm_seg1_threads() { return 256; }
 // scalars per thread of the level-1 passes: 8 from 2^20 terms on; a short MSM (an index shard) gets fewer, so that its
 // level-1 launches still have 512 workgroups -- at 2^17 terms 8 per thread is 64 workgroups and 34 + 39 us for the
 // histogram and the scatter, 1 per thread 512 workgroups (profiles/r03_shard_timeline.txt)
 inline uint32_t msm_seg1_per_thread(uint64_t m) {
-    static const uint32_t forced = [] {
-        const char* e = getenv("TYPLONK_SEG1_PER_THREAD");
-        const int v = e ? atoi(e) : 0;
-        return (uint32_t)((v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0);
-    }();
-    if (forced) return forced;
     // (2^19-term chunks keep 8: their scatter, 4096 segments wide, wants long runs per workgroup and segment)
     return m <= (1u << 17) ? 1u : (m <= (1u << 18) ? 2u : 8u);
 }
@@ -509,40 +491,7 @@ __global__ __launch_bounds__(256) void order_hist_kernel(const uint32_t* counts,
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
-// single block: base[s] = number of buckets with a larger size key (descending order)
-__global__ __launch_bounds__(256) void order_scan_kernel(const uint32_t* hist, uint32_t* base) {
-    __shared__ uint32_t buf[256];
-    const uint32_t k = 255 - threadIdx.x;  // thread t handles size key 255 - t
-    const uint32_t v = hist[k];
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-        __syncthreads();
-        buf[threadIdx.x] += t;
-        __syncthreads();
-    }
-    base[k] = buf[threadIdx.x] - v;
-}
-__global__ __launch_bounds__(256) void order_scatter_kernel(const uint32_t* counts, uint32_t n, uint32_t* base,
-                                                            uint32_t* order) {
-    __shared__ uint32_t h[256];
-    __shared__ uint32_t blk[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    uint32_t key = 0, rank = 0;
-    if (g < n) {
-        key = min(counts[g], 255u);
-        rank = atomicAdd(&h[key], 1u);
-    }
-    __syncthreads();
-    if (h[threadIdx.x]) blk[threadIdx.x] = atomicAdd(&base[threadIdx.x], h[threadIdx.x]);
-    __syncthreads();
-    if (g < n) order[blk[key] + rank] = g;
-}
-
-// order_scan_kernel + order_scatter_kernel in one launch: every workgroup scans the (complete) 256-bin size histogram
+// Bucket schedule in one launch: every workgroup scans the (complete) 256-bin size histogram
 // for itself and claims its run inside each bin from a zero-initialised global cursor (hist514[256..511])
 __global__ __launch_bounds__(256) void order_fused_kernel(const uint32_t* counts, uint32_t n, const uint32_t* hist,
                                                           uint32_t* gcur, uint32_t* order) {
@@ -630,9 +579,9 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
     sh.nblk = (uint32_t)((m + sh.chunk - 1) / sh.chunk);
     const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
     const uint32_t nt1 = msm_seg1_threads();
-    static const bool scan3 = [] { const char* e = getenv("TYPLONK_MSM_SCAN"); return e && strcmp(e, "scan3") == 0; }();
-    // the fused row-prefix form scans the segment totals in LDS next to the scatter's cursors (nseg + nt1 words)
-    const bool fused = !scan3 && sh.nseg <= 8192;
+    // the fused row-prefix form scans the segment totals in LDS next to the scatter's cursors (nseg + nt1 words); wider
+    // segment sets take the three-launch scan of the whole workgroup x segment matrix
+    const bool fused = sh.nseg <= 8192;
     uint32_t* seg_tot = fused ? scan_scratch : nullptr;
     hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
                        blk_hist);
@@ -658,12 +607,6 @@ void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32
     if (!hist_done) {
         (void)hipMemsetAsync(hist514, 0, 516 * sizeof(uint32_t), s);
         hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, offsets, n, cap, hist514, heavy, tasks);
-    }
-    static const bool split = [] { const char* e = getenv("TYPLONK_MSM_ORDER"); return e && strcmp(e, "split") == 0; }();
-    if (split) {  // the two-launch form (A/B measurements)
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(256), 0, s, hist514, hist514 + 256);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514 + 256, order);
-        return;
     }
     hipLaunchKernelGGL(order_fused_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514, hist514 + 256, order);
 }

@@ -25,8 +25,6 @@ struct NttPassArgs {
     const Fr* post_hi;
     const Fr* scale;   // n^-1 applied to the output of the last pass (plain inverse NTT)
     uint32_t pre_h, post_h;
-    uint32_t radix4;      // 0: one LDS round trip per stage; 1: register-resident radix-4 stage groups (ntt_kernels.hip);
-                          // 2: the same with the first group fed from global memory and the last one storing to it
     // Full (one multiplication) tables, built once per size in HBM and laid out exactly like the data they
     // multiply, so their loads coalesce with the data's.  NULL = compose the factor from the two-level tables.
     const Fr* tw_full;    // inter-pass twiddles of this pass: [k_p * S + column], row_len entries

@@ -37,7 +37,7 @@ __device__ __forceinline__ Fr ntt_pow2l(const Fr* lo, const Fr* hi, uint32_t h, 
 }
 
 // ---- register-resident radix-4 stage groups -------------------------------------------------------------------------
-// The radix-2 form below makes one LDS round trip (two loads, two stores, a __syncthreads) per stage: ten per 2^10-point
+// A radix-2 stage makes one LDS round trip (two loads, two stores, a __syncthreads): ten per 2^10-point
 // sub-transform.  Here a thread takes the four elements of two consecutive DIF stages -- i0 + j * quarter, j = 0..3,
 // quarter = half / 2 -- does both stages in registers and stores them back in place: five round trips for k = 10, the
 // same multiplications in the same order on every element (so the results, and the lazy bounds of the 30-bit form,
@@ -148,7 +148,7 @@ __device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A
 }
 
 // 256 threads on tiles of <= 1024 elements (32 KiB of LDS), or 1024 threads on tiles of <= 4096 elements (128 KiB:
-// one workgroup per CU) when a 2^17..2^20 transform is done in two passes instead of three (capi.hip, ntt_run)
+// one workgroup per CU) when a 2^17..2^20 transform is done in two passes instead of three (ntt_host.hip, ntt_run)
 __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     const uint32_t NTT_THREADS = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
             ntt_st(a.out + o, x);
         }
     };
-    const bool direct = a.radix4 == 2 && k >= 2;
+    const bool direct = k >= 2;   // (k = 1: a single radix-2 stage through the LDS tile)
     if (!direct) {
         if (!a.last) {
             for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) ntt_st(tile + idx, gload(idx >> logT, idx & (T - 1)));
@@ -208,45 +208,12 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     }
     __syncthreads();   // (direct: the sub-transform's twiddles are in LDS)
 
-    // k radix-2 DIF stages, natural order in, bit-reversed order out (within the tile).
+    // k DIF stages as register-resident radix-4 groups, natural order in, bit-reversed order out (within the tile).
     // The twiddle of a butterfly is w^(pos << s) with pos < half: it is 1 for pos = 0, i.e. for EVERY butterfly of the
-    // last stage (half = 1) and for every other one of the stage before (half = 2).  Those multiplications are
-    // skipped -- 0.75 of the k/2 multiplications per element of a pass (19 % of a 2^20 transform's).  For half = 2 the
-    // butterflies are dealt out so that a whole sweep of the workgroup has the same pos (no divergence inside a wave).
-    const uint32_t nb = E >> 1;
-    if (a.radix4) ntt_stages_radix4<NttArith32>(tile, stw, k, logT, E, tid, NTT_THREADS, direct, a.last != 0, gload, gstore);
+    // last stage (half = 1) and for every other one of the stage before (half = 2); those multiplications are skipped --
+    // 0.75 of the k/2 multiplications per element of a pass (19 % of a 2^20 transform's).
+    ntt_stages_radix4<NttArith32>(tile, stw, k, logT, E, tid, NTT_THREADS, direct, a.last != 0, gload, gstore);
     if (direct) return;
-    for (uint32_t s = a.radix4 ? k : 0u; s < k; ++s) {
-        const uint32_t lh = k - 1 - s;  // log2(half)
-        const uint32_t half = 1u << lh;
-        const bool split = (lh == 1) && (nb >= 2 * NTT_THREADS);  // sweep 2r: pos 0, sweep 2r + 1: pos 1
-        for (uint32_t qq = tid; qq < nb; qq += NTT_THREADS) {
-            uint32_t t, j;
-            if (split) {
-                const uint32_t sweep = qq / NTT_THREADS;               // uniform across the workgroup
-                const uint32_t q2 = (sweep >> 1) * NTT_THREADS + tid;  // index among the butterflies of one parity
-                t = q2 & (T - 1);
-                j = ((q2 >> logT) << 1) | (sweep & 1u);
-            } else {
-                t = qq & (T - 1);
-                j = qq >> logT;
-            }
-            const uint32_t pos = j & (half - 1);
-            const uint32_t i0 = ((j >> lh) << (lh + 1)) + pos;
-            Fr* pa = tile + ((i0 << logT) + t);
-            Fr* pb = tile + (((i0 + half) << logT) + t);
-            const Fr x = ntt_ld(pa), y = ntt_ld(pb);
-            ntt_st(pa, fe_add(x, y));
-            const Fr d = fe_sub(x, y);
-            if (lh == 0 || (split && pos == 0)) {
-                ntt_st(pb, d);  // twiddle 1
-            } else {
-                ntt_st(pb, fe_mul(d, ntt_ld(stw + (pos << s))));
-            }
-        }
-        __syncthreads();
-    }
-
     for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
         const uint32_t t = idx & (T - 1), kk = idx >> logT;
         const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
@@ -256,7 +223,7 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
 
 // ---- the same pass on 9 x 30-bit limbs (fr30.hpp) -------------------------------------------------------------------
 // Same tiling, addressing and stage order as ntt_pass_kernel.  The LDS tile holds 9 words per element; every table
-// (sub_tw, tw_full, pre_full, post_full, scale) is in the 2^270 domain and must be a full table (capi.hip selects this
+// (sub_tw, tw_full, pre_full, post_full, scale) is in the 2^270 domain and must be a full table (ntt_host.hip selects this
 // kernel only then).  Additions are lazy (fr30.hpp states the bounds); a pass ends with a multiplication of every
 // element -- the inter-pass twiddle, the coset / scaling factor of the last pass, or 2^270 mod r when the last pass has
 // no factor -- which brings it below 2r; the last pass then subtracts r once more where needed, so that what reaches
@@ -314,7 +281,7 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
             ntt_st(a.out + o, fr30_to_canonical(x));
         }
     };
-    const bool direct = a.radix4 == 2 && k >= 2;
+    const bool direct = k >= 2;   // (k = 1: a single radix-2 stage through the LDS tile)
     if (!direct) {
         if (!a.last) {
             for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) lds_st30(tile + 9 * idx, gload(idx >> logT, idx & (T - 1)));
@@ -327,39 +294,8 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     }
     __syncthreads();
 
-    const uint32_t nb = E >> 1;
-    if (a.radix4) ntt_stages_radix4<NttArith30>(tile, stw, k, logT, E, tid, NTT_THREADS, direct, a.last != 0, gload, gstore);
+    ntt_stages_radix4<NttArith30>(tile, stw, k, logT, E, tid, NTT_THREADS, direct, a.last != 0, gload, gstore);
     if (direct) return;
-    for (uint32_t s = a.radix4 ? k : 0u; s < k; ++s) {
-        const uint32_t lh = k - 1 - s;
-        const uint32_t half = 1u << lh;
-        const bool split = (lh == 1) && (nb >= 2 * NTT_THREADS);
-        for (uint32_t qq = tid; qq < nb; qq += NTT_THREADS) {
-            uint32_t t, j;
-            if (split) {
-                const uint32_t sweep = qq / NTT_THREADS;
-                const uint32_t q2 = (sweep >> 1) * NTT_THREADS + tid;
-                t = q2 & (T - 1);
-                j = ((q2 >> logT) << 1) | (sweep & 1u);
-            } else {
-                t = qq & (T - 1);
-                j = qq >> logT;
-            }
-            const uint32_t pos = j & (half - 1);
-            const uint32_t i0 = ((j >> lh) << (lh + 1)) + pos;
-            uint32_t* pa = tile + 9 * ((i0 << logT) + t);
-            uint32_t* pb = tile + 9 * (((i0 + half) << logT) + t);
-            const Fr30 x = lds_ld30(pa), y = lds_ld30(pb);
-            lds_st30(pa, fr30_add(x, y));
-            const Fr30 d = fr30_sub(x, y);
-            if (lh == 0 || (split && pos == 0)) {
-                lds_st30(pb, d);  // twiddle 1
-            } else {
-                lds_st30(pb, fr30_mul(d, lds_ld30(stw + 9 * (pos << s))));
-            }
-        }
-        __syncthreads();
-    }
     for (uint32_t idx = tid; idx < E; idx += NTT_THREADS) {
         const uint32_t t = idx & (T - 1), kk = idx >> logT;
         const uint32_t src = (k ? (__brev(kk) >> (32 - k)) : 0u);
