@@ -167,3 +167,17 @@ def test_both_butterfly_kernels_give_the_c_oracles_words(built, mode, monkeypatc
                 assert (c2.ntt(top, log_n) == CO.ntt(top, log_n)).all(), (mode, log_n, "all r-1")
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("log_n", [26, 27])
+def test_beyond_the_full_table_limit_vs_c_oracle(ctx, log_n):
+    """typlonk_ntt_fr accepts every two-adic size; above 2^24 points the inter-pass twiddles are composed from two-level
+    tables instead of read from a full table, and four passes are needed.  Whole-vector equality with the C restatement
+    (its OpenMP form: the one-thread form takes a minute here) at 2^26 and 2^27 (a 4-GiB vector), forward, and the
+    inverse round trip."""
+    from oracle import coracle as CO
+
+    x = rand_limbs(2000 + log_n, 1 << log_n)
+    f = ctx.ntt(x, log_n)
+    assert (f == CO.ntt(x, log_n, threads=0)).all()
+    assert (ctx.ntt(f, log_n, inverse=True) == x).all()

@@ -1,5 +1,5 @@
 """Instruction mix of the steady-state path of a kernel's inner loop, from `hipcc -S` output, priced with the per-instruction
-issue times of the integer-pipe micro-benchmark (tools/ubench.hip, profiles/r01_ubench_v2_madadd.txt) -- an
+issue costs of the round-4 pricing micro-benchmark (tools/ubench4.hip, profiles/r04_ubench4_pricing.txt) -- an
 instruction-count ceiling that does not come from timing the same loop.
 
 usage: python tools/isa_count.py <file.s> <kernel-substring> <units-per-iteration> [block labels of the hot path ...]
@@ -8,11 +8,24 @@ path can be picked by reading the listing."""
 import json, re, sys
 from collections import Counter
 
-# ns per wave-instruction on one SIMD = measured "cyc/wave-instr/SIMD" at the nominal 2400 MHz / 2.4
-UBENCH_NS = {"v_mad_u64_u32": 5.26 / 2.4, "v_mul_lo_u32": 4.79 / 2.4, "v_mul_hi_u32": 4.59 / 2.4, "v_add_u32": 3.42 / 2.4,
-             "v_lshrrev_b64": 4.53 / 2.4, "v_lshl_add_u64": 4.93 / 2.4, "v_alignbit_b32": 4.42 / 2.4,
-             "v_and_b32": 2.61 / 2.4, "v_mov_b32": 3.01 / 2.4}
-DEFAULT_NS = 3.42 / 2.4   # other VALU instructions: priced like v_add_u32
+# Price list (round 4): cycles per wave-instruction per SIMD at saturation, measured with s_memtime per physical SIMD and an
+# occupancy sweep (tools/ubench4.hip -> profiles/r04_ubench4_pricing.txt, the W = 8 column).  Three classes fall out:
+#   full rate  (VOP2 add / sub / and / xor / shifts by register, mov)            2.20 cycles  (the guide's 2-cycle wave64 issue)
+#   half rate  (v_mul_lo/hi_u32, 64-bit shifts and adds, v_add3, v_alignbit, v_mad_u32_u24, v_or3, v_fma_f64)   4.12 cycles
+#   v_mad_u64_u32 and the carry ops that follow it (v_addc_co_u32 ...)            4.27 cycles
+# The clock is the one the same instruction mix ran at in that micro-benchmark (g1_madd row: 2061 MHz; the multiplier
+# stream is power-limited below the 2400 MHz maximum), so a ceiling in units/s is cycles and that clock, nothing else.
+CLOCK_HZ = 2.061e9
+FULL, HALF, MAD = 2.20, 4.12, 4.27
+CYCLES = {"v_mad_u64_u32": MAD, "v_addc_co_u32": MAD, "v_subb_co_u32": MAD, "v_subbrev_co_u32": MAD, "v_add_co_u32": MAD,
+          "v_sub_co_u32": MAD, "v_subrev_co_u32": MAD,
+          "v_mul_lo_u32": HALF, "v_mul_hi_u32": HALF, "v_lshrrev_b64": HALF, "v_lshlrev_b64": HALF, "v_lshl_add_u64": HALF,
+          "v_add3_u32": HALF, "v_alignbit_b32": HALF, "v_mad_u32_u24": HALF, "v_or3_b32": HALF, "v_fma_f64": HALF,
+          "v_lshlrev_b32": HALF, "v_lshl_add_u32": HALF, "v_lshl_or_b32": HALF, "v_and_or_b32": HALF, "v_bfe_u32": HALF,
+          "v_add_lshl_u32": HALF, "v_xad_u32": HALF, "v_mad_u64_u32_e64": MAD}
+DEFAULT_CYCLES = FULL   # the remaining VOP1 / VOP2 forms (v_add_u32, v_sub_u32, v_and_b32, v_mov_b32, v_cndmask_b32, shifts ...)
+UBENCH_NS = {k: v / CLOCK_HZ * 1e9 for k, v in CYCLES.items()}
+DEFAULT_NS = DEFAULT_CYCLES / CLOCK_HZ * 1e9
 
 
 def main():
@@ -54,7 +67,12 @@ def main():
            "ns_per_wave_iteration_multiplier_only": t_mad, "ns_per_wave_iteration_all_valu": t_all,
            "ceiling_units_per_s_multiplier_only": simds * lanes * units / (t_mad * 1e-9),
            "ceiling_units_per_s_all_valu": simds * lanes * units / (t_all * 1e-9),
-           "pricing": "ns per wave-instruction per SIMD from tools/ubench (profiles/r01_ubench_v2_madadd.txt); 1024 SIMDs x 64 lanes"}
+           "cycles_per_wave_iteration_multiplier_only": mix["v_mad_u64_u32"] * MAD,
+           "cycles_per_wave_iteration_all_valu": sum(v * CYCLES.get(k, DEFAULT_CYCLES) for k, v in valu.items()),
+           "clock_hz": CLOCK_HZ, "cycles_full_half_mad": [FULL, HALF, MAD],
+           "pricing": "cycles per wave-instruction per SIMD at saturation, s_memtime per physical SIMD, occupancy sweep "
+                      "(tools/ubench4.hip, profiles/r04_ubench4_pricing.txt); clock = the one the g1_madd micro-kernel ran at; "
+                      "1024 SIMDs x 64 lanes"}
     print(json.dumps(out, indent=1))
 
 

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "../typlonk_amd/csrc/g1.hpp"
@@ -28,8 +29,23 @@ constexpr int CH = 8;      // independent chains per lane
 constexpr int REP = 8;     // CH * REP instructions per loop iteration
 
 struct Rec {
-    uint64_t cycles, wall;
+    uint64_t t0, t1, wall;
+    uint32_t hw_id, xcc_id;   // HW_REG_HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; HW_REG_XCC_ID: xcc[3:0]
 };
+__device__ __forceinline__ void rec_store(Rec* out, uint64_t t0, uint64_t t1, uint64_t w0, uint64_t w1, uint32_t sink) {
+    if ((threadIdx.x & 63) == 0) {
+        Rec r;
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        r.t0 = t0;
+        r.t1 = t1 + (sink == 0x12345u ? 1 : 0);
+        r.wall = w1 - w0;
+        r.hw_id = hw;
+        r.xcc_id = xcc;
+        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = r;
+    }
+}
 
 enum Op { MAD64 = 0, MUL_LO, MUL_HI, ADD, AND, MOV, LSHR64, LSHL_ADD64, ADDC, ADD3, SUB, ASHR, LSHL, CNDMASK, FMA64, ALIGNBIT, MAD24, XOR, OR3, N_OPS };
 static const char* OP_NAMES[N_OPS] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add_u32", "v_and_b32", "v_mov_b32", "v_lshrrev_b64",
@@ -79,12 +95,7 @@ __global__ __launch_bounds__(256) void op_kernel(Rec* out, int iters) {
     const uint64_t w1 = wall_clock64();
     uint32_t s = 0;
     for (int j = 0; j < CH; ++j) s += (uint32_t)acc[j] + (uint32_t)(acc[j] >> 32) + x[j] + (uint32_t)d[j];
-    if ((threadIdx.x & 63) == 0) {
-        Rec r;
-        r.cycles = t1 - t0 + (s == 0x12345u ? 1 : 0);
-        r.wall = w1 - w0;
-        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = r;
-    }
+    rec_store(out, t0, t1, w0, w1, s);
 }
 
 // ---- instruction mixes (pipe cost only) -------------------------------------------------------------------------------
@@ -134,18 +145,13 @@ __global__ __launch_bounds__(256) void mix_kernel(Rec* out, int iters) {
     const uint64_t t1 = __builtin_readcyclecounter();
     const uint64_t w1 = wall_clock64();
     const uint32_t s = (uint32_t)acc0 + (uint32_t)acc1 + dig + (uint32_t)s0 + (uint32_t)s1 + (uint32_t)h + (uint32_t)l + a;
-    if ((threadIdx.x & 63) == 0) {
-        Rec r;
-        r.cycles = t1 - t0 + (s == 0x12345u ? 1 : 0);
-        r.wall = w1 - w0;
-        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = r;
-    }
+    rec_store(out, t0, t1, w0, w1, s);
 }
 
 // ---- field-level costs in cycles: one Fq multiplication, one mixed addition, one SIMT inversion (Fermat ladder) -------
 // KIND 0: 64 dependent fq30_mul; 1: 64 dependent fq30_sqr; 2: 16 g1_madd on a register accumulator; 3: one fq30_inv_fermat
-template <int KIND>
-__global__ __launch_bounds__(256) void field_kernel(Rec* out, int iters) {
+template <int KIND, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void field_kernel(Rec* out, int iters) {
     extern __shared__ char lds_hold[];
     Fq30 a, b;
     for (int i = 0; i < 13; ++i) { a.v[i] = (threadIdx.x * 77u + i * 13u + 1) & FQ30_MASK; b.v[i] = (blockIdx.x * 31u + i * 7u + 3) & FQ30_MASK; }
@@ -169,49 +175,65 @@ __global__ __launch_bounds__(256) void field_kernel(Rec* out, int iters) {
     const uint64_t w1 = wall_clock64();
     uint32_t s = 0;
     for (int i = 0; i < 13; ++i) s += a.v[i] ^ b.v[i] ^ acc.x.v[i] ^ acc.zz.v[i];
-    if ((threadIdx.x & 63) == 0) {
-        Rec r;
-        r.cycles = t1 - t0 + (s == 0x12345u ? 1 : 0);
-        r.wall = w1 - w0;
-        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = r;
-    }
+    rec_store(out, t0, t1, w0, w1, s);
 }
 
+
 struct Result {
-    double cyc_per_unit_per_simd, mhz;
+    double cyc_per_unit_per_simd, mhz, waves_per_simd;
 };
 
+// Per physical SIMD (xcc, se, sh, cu, simd from the hardware id registers): units executed by the wavefronts that ran on
+// it / (last end - first start).  The figure reported is the median over the SIMDs that held the intended number of
+// wavefronts at once -- it does not depend on how the dispatcher spread the workgroups.
 template <class K>
 static int run(K kern, int W, int iters, double units_per_wave, Result* res) {
     int cus = 0;
     CHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-    // LDS per workgroup such that exactly W workgroups of 256 threads fit the 160 KiB of a CU
-    const size_t lds = std::min<size_t>(64 * 1024, (size_t)(160 * 1024 / W) - 512);
+    // LDS per workgroup such that at most W workgroups of 256 threads fit the 160 KiB of a CU
+    const size_t lds = std::min<size_t>(160 * 1024 - 1024, (size_t)(160 * 1024 / W) - 1024);
     CHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int blocks = cus * W;
     Rec* d = nullptr;
     CHK(hipMalloc((void**)&d, sizeof(Rec) * blocks * 4));
     std::vector<Rec> h(blocks * 4);
-    double best = 1e30, mhz = 0;
+    double best = 1e30, mhz = 0, wps = 0;
     for (int rep = 0; rep < 4; ++rep) {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d, iters);
         CHK(hipDeviceSynchronize());
         CHK(hipMemcpy(h.data(), d, sizeof(Rec) * blocks * 4, hipMemcpyDeviceToHost));
-        // median over the wavefronts: every SIMD holds W of them for (nearly) the same interval
-        std::vector<double> cyc(blocks * 4);
-        double wall = 0;
-        for (int i = 0; i < blocks * 4; ++i) { cyc[i] = (double)h[i].cycles; wall += (double)h[i].wall; }
-        std::nth_element(cyc.begin(), cyc.begin() + cyc.size() / 2, cyc.end());
-        const double med = cyc[cyc.size() / 2];
-        double csum = 0;
-        for (int i = 0; i < blocks * 4; ++i) csum += (double)h[i].cycles;
-        const double m = csum / (wall / 100e6) / 1e6;   // shader cycles per second of the constant 100 MHz clock
-        const double v = med / (W * units_per_wave);
-        if (rep > 0 && v < best) { best = v; mhz = m; }
+        std::map<uint32_t, std::vector<int>> by_simd;
+        double csum = 0, wall = 0;
+        for (int i = 0; i < blocks * 4; ++i) {
+            const uint32_t key = ((h[i].xcc_id & 0xf) << 16) | (h[i].hw_id & 0xff30u);   // se, sh, cu, simd
+            by_simd[key].push_back(i);
+            csum += (double)(h[i].t1 - h[i].t0);
+            wall += (double)h[i].wall;
+        }
+        std::vector<double> per, cnt;   // per SIMD: cycles per unit, wavefronts it held
+        for (auto& kv : by_simd) {
+            uint64_t a = ~0ull, b = 0;
+            for (int i : kv.second) {
+                a = std::min(a, h[i].t0);
+                b = std::max(b, h[i].t1);
+            }
+            per.push_back((double)(b - a) / ((double)kv.second.size() * units_per_wave));
+            cnt.push_back((double)kv.second.size());
+        }
+        if (per.empty()) continue;
+        std::nth_element(per.begin(), per.begin() + per.size() / 2, per.end());
+        const double v = per[per.size() / 2];
+        if (rep > 0 && v < best) {
+            best = v;
+            mhz = csum / (wall / 100e6) / 1e6;   // shader cycles per second of the constant 100 MHz clock
+            std::nth_element(cnt.begin(), cnt.begin() + cnt.size() / 2, cnt.end());
+            wps = cnt[cnt.size() / 2];
+        }
     }
     CHK(hipFree(d));
     res->cyc_per_unit_per_simd = best;
     res->mhz = mhz;
+    res->waves_per_simd = wps;
     return 0;
 }
 
@@ -223,7 +245,7 @@ static int sweep_op(const int* Ws, int nW) {
         Result r;
         if (run(op_kernel<OP>, Ws[k], iters, (double)iters * CH * REP, &r)) return 1;
         printf("  %6.2f", r.cyc_per_unit_per_simd);
-        if (k == nW - 1) printf("   (%4.0f MHz)", r.mhz);
+        if (k == nW - 1) printf("   (%4.0f MHz, %g waves/SIMD seen)", r.mhz, r.waves_per_simd);
     }
     printf("\n");
     fflush(stdout);
@@ -267,30 +289,31 @@ int main() {
         printf("\n");
         fflush(stdout);
     }
-    printf("\nfield level, cycles per wave per SIMD and unit\n");
-    printf("%-44s  %6s  %6s\n", "unit", "W=1", "W=2");
-    const int Wf[2] = {1, 2};
-    double mul2 = 0, inv2 = 0, madd2 = 0;
+    printf("\nfield level: cycles per wave per SIMD and unit; W wavefronts per SIMD, registers budgeted for W (spills: see -Rpass-analysis)\n");
+    printf("%-44s  %7s  %7s  %7s  %7s\n", "unit", "W=1", "W=2", "W=3", "W=4");
+    const char* names[4] = {"fq30_mul (fused product + reduction)", "fq30_sqr", "g1_madd (XYZZ += affine, 8M + 2S)", "fq30_inv_fermat (one SIMT inversion)"};
+    const double units[4] = {64.0, 64.0, 16.0, 1.0};
+    const int its[4] = {20, 20, 10, 2};
+    double tab[4][4];
     for (int kind = 0; kind < 4; ++kind) {
-        const char* names[4] = {"fq30_mul (fused product + reduction)", "fq30_sqr", "g1_madd (XYZZ += affine, 8M + 2S)", "fq30_inv_fermat (one SIMT inversion)"};
-        const double units[4] = {64.0, 64.0, 16.0, 1.0};
-        const int iters[4] = {20, 20, 10, 2};
         printf("%-44s", names[kind]);
-        for (int k = 0; k < 2; ++k) {
+        for (int w = 1; w <= 4; ++w) {
             Result r;
-            int rc = kind == 0 ? run(field_kernel<0>, Wf[k], iters[kind], units[kind] * iters[kind], &r)
-                   : kind == 1 ? run(field_kernel<1>, Wf[k], iters[kind], units[kind] * iters[kind], &r)
-                   : kind == 2 ? run(field_kernel<2>, Wf[k], iters[kind], units[kind] * iters[kind], &r)
-                               : run(field_kernel<3>, Wf[k], iters[kind], units[kind] * iters[kind], &r);
+            int rc = 1;
+#define FK(K, WV) if (kind == K && w == WV) rc = run(field_kernel<K, WV>, WV, its[K], units[K] * its[K], &r)
+            FK(0, 1); FK(0, 2); FK(0, 3); FK(0, 4); FK(1, 1); FK(1, 2); FK(1, 3); FK(1, 4);
+            FK(2, 1); FK(2, 2); FK(2, 3); FK(2, 4); FK(3, 1); FK(3, 2); FK(3, 3); FK(3, 4);
+#undef FK
             if (rc) return 1;
-            printf("  %6.0f", r.cyc_per_unit_per_simd);
-            if (k == 1) { if (kind == 0) mul2 = r.cyc_per_unit_per_simd; if (kind == 2) madd2 = r.cyc_per_unit_per_simd; if (kind == 3) inv2 = r.cyc_per_unit_per_simd; }
-            if (k == 1) printf("   (%4.0f MHz)", r.mhz);
+            tab[kind][w - 1] = r.cyc_per_unit_per_simd;
+            printf("  %7.0f", r.cyc_per_unit_per_simd);
+            if (w == 4) printf("   (%4.0f MHz, %g waves/SIMD seen)", r.mhz, r.waves_per_simd);
         }
         printf("\n");
         fflush(stdout);
     }
-    printf("\none SIMT inversion = %.0f multiplication times; one mixed addition = %.2f multiplication times\n", inv2 / mul2, madd2 / mul2);
-    printf("chip-wide at W=2: %.2f G mixed additions/s per GHz of shader clock (1024 SIMDs x 64 lanes / cycles)\n", 1024.0 * 64 / madd2);
+    printf("\none SIMT inversion = %.0f multiplication times (W=2); one mixed addition = %.2f multiplication times\n", tab[3][1] / tab[0][1], tab[2][1] / tab[0][1]);
+    for (int w = 1; w <= 4; ++w)
+        printf("chip-wide at W=%d: %.2f G mixed additions/s per GHz of shader clock (1024 SIMDs x 64 lanes / cycles)\n", w, 1024.0 * 64 / tab[2][w - 1]);
     return 0;
 }

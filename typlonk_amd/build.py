@@ -67,6 +67,32 @@ def build_hip(force: bool = False) -> str:
     return LIB
 
 
+def build_hip_variant(name: str, unit_flags: dict[str, list[str]]) -> str:
+    """a second build of the library under tools/_ab/<name>/ with extra per-unit flags: same-box A/B measurements load it
+    through TYPLONK_LIB_PATH (python -m typlonk_amd.build variant <name> <unit.hip>:<flag>[,<flag>] ...)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    out_dir = os.path.join(ROOT, "tools", "_ab", name)
+    os.makedirs(out_dir, exist_ok=True)
+    hipcc = hipcc_path()
+    base_obj = os.path.join(CSRC, "_obj")
+    jobs, objs = [], []
+    for u in HIP_UNITS:
+        if u in unit_flags:
+            obj = os.path.join(out_dir, u.replace(".hip", ".o"))
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *UNIT_FLAGS.get(u, []), *unit_flags[u], "-c",
+                         os.path.join(CSRC, u), "-o", obj])
+        else:
+            obj = os.path.join(base_obj, u.replace(".hip", ".o"))   # the default build's object
+        objs.append(obj)
+    build_hip()
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(_run, jobs))
+    lib = os.path.join(out_dir, "libtyplonk_hip.so")
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
+
+
 def build_host_shim(force: bool = False) -> str:
     src = os.path.join(ROOT, "tests", "cpp", "ff_host_shim.cpp")
     out = os.path.join(ROOT, "tests", "cpp", "libff_host_shim.so")
@@ -102,4 +128,13 @@ def build_all(force: bool = False) -> None:
 
 
 if __name__ == "__main__":
-    build_all()
+    import sys
+
+    if len(sys.argv) >= 3 and sys.argv[1] == "variant":
+        flags: dict[str, list[str]] = {}
+        for spec in sys.argv[3:]:
+            unit, _, fl = spec.partition(":")
+            flags[unit] = [f for f in fl.split(",") if f]
+        print(build_hip_variant(sys.argv[2], flags))
+    else:
+        build_all()

@@ -28,7 +28,11 @@ __device__ __forceinline__ G1Affine unpack_point(const PackedPoint& p) {
     return r;
 }
 
-__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accum_kernel(const uint32_t* __restrict__ points,
+// wavefronts per SIMD the compiler budgets registers for (512 / MSM_ACC_WAVES VGPRs per lane, spilling what does not fit)
+#ifndef MSM_ACC_WAVES
+#define MSM_ACC_WAVES 2
+#endif
+__global__ __launch_bounds__(MSM_ACC_THREADS) __attribute__((amdgpu_waves_per_eu(MSM_ACC_WAVES, MSM_ACC_WAVES))) void msm_accum_kernel(const uint32_t* __restrict__ points,
                                                                     const uint32_t* __restrict__ offsets,
                                                                     const uint32_t* __restrict__ sorted,
                                                                     const uint32_t* __restrict__ order,
