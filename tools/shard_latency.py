@@ -73,4 +73,29 @@ t0 = time.perf_counter()
 for _ in range(reps):
     ctx.msm_sharded_devptr(sh.sid, full.data_ptr(), n)
 out["sharded_msm_wall_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+# the BATCHED shard rate: nine MSMs in flight per rank (a prover round's worth, three lanes) and ONE exchange for all nine --
+# the mode in which the latency tails of a short MSM (sort, reduction, host finish, exchange) hide behind other MSMs'
+# accumulations; prove() issues its commitments this way
+nb = 9
+ptrs, ms = [full.data_ptr()] * nb, [n - (k % 3) for k in range(nb)]
+for _ in range(3):
+    ctx.msm_sharded_batch_devptr(sh.sid, ptrs, ms)
+t0 = time.perf_counter()
+breps = max(3, reps // 10)
+for _ in range(breps):
+    ctx.msm_sharded_batch_devptr(sh.sid, ptrs, ms)
+out["sharded_batch9_ms_per_msm"] = round((time.perf_counter() - t0) / breps / nb * 1e3, 4)
+# one rank's share of a sharded prove(): NTTs, grand product and quotient are replicated, the 13 commitments run on the
+# shard, three exchanges (on the one-rank communicator) -- the per-rank time of BASELINE config 4 / 5 without wire time
+if os.environ.get("NO_PROVE") != "1":
+    from typlonk_amd.circuits import SquaringChain
+    chain = SquaringChain(ctx, log_n)
+    for _ in range(2):
+        ctx.prove_native(sh.sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.prove_native(sh.sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+    out["prove_on_shard_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    chain.free()
 print("SHARD " + json.dumps(out))
