@@ -44,14 +44,15 @@ FR_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
 # What actually bounds the accumulation (and the NTT) is the vector ALU.  The ceilings are INSTRUCTION COUNTS x a price
-# list, not timings of the same loops: the steady-state path of msm_accum_kernel's inner loop holds 3081 v_mad_u64_u32
-# per mixed addition (4818 VALU instructions in all; `hipcc -S` listing read by tools/isa_count.py ->
-# profiles/r04_isa_msm_accum.json).  The price list is round 4's (tools/ubench4.hip, profiles/r04_ubench4_pricing.txt):
-# cycles per wave-instruction per SIMD at saturation, counted with s_memtime per physical SIMD over an occupancy sweep --
-# 2.20 for full-rate VOP2 (the guide's 2-cycle wave64 issue), 4.12 for the half-rate class, 4.27 for v_mad_u64_u32 and the
-# carry ops -- at the clock that instruction mix ran at there (2061 MHz; the multiplier stream is power-limited).  With
-# 1024 SIMDs x 64 lanes: 10.27 G mixed additions/s if only the multiplier instructions issued, 7.21 G/s for all 4818
-# instructions (the whole-addition micro-kernel of the same file measures 19.5 k cycles against the model's 18.7 k).
+# list x the chip's maximum clock, not timings of the same loops: the steady-state path of msm_accum_kernel's inner loop
+# holds 3081 v_mad_u64_u32 per mixed addition (4818 VALU instructions in all; `hipcc -S` listing read by
+# tools/isa_count.py -> profiles/r04_isa_msm_accum.json).  The price list is round 4's (tools/ubench4.hip,
+# profiles/r04_ubench4_pricing.txt): cycles per wave-instruction per SIMD at saturation, counted with s_memtime per
+# physical SIMD over an occupancy sweep -- 2.20 for full-rate VOP2 (the guide's 2-cycle wave64 issue), 4.12 for the
+# half-rate class, 4.27 for v_mad_u64_u32 and the carry ops.  At the 2400 MHz maximum clock and 1024 SIMDs x 64 lanes:
+# 11.96 G mixed additions/s if only the multiplier instructions issued, 8.40 G/s for all 4818 instructions (18.7 k cycles
+# per wavefront and addition; the whole-addition micro-kernel of the same file measures 19.5 k).  The kernel itself is
+# power-limited to 2.06-2.2 GHz: that shortfall is part of the distance to either ceiling.
 def _isa(name: str, key: str, default):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -60,12 +61,12 @@ def _isa(name: str, key: str, default):
         return default
 
 
-MIXED_ADD_MULTIPLIER_CEILING = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_multiplier_only", 10.267e9))
-MIXED_ADD_ALL_VALU_MODEL = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_all_valu", 7.212e9))
+MIXED_ADD_MULTIPLIER_CEILING = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_multiplier_only", 11.956e9))
+MIXED_ADD_ALL_VALU_MODEL = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_all_valu", 8.398e9))
 # the same for one Fr multiplication inside the NTT butterflies (profiles/r04_isa_ntt.json: 64 v_mad_u64_u32 of the product
-# scan + 64 of the reduction = 128 per multiplication, each followed by a carry op of the same price; 2.2 GHz)
-FR_MUL_MULTIPLIER_CEILING = float(_isa("r04_isa_ntt.json", "ceiling_fr_mul_per_s_multiplier_only", 2.638e11))
-FR_MUL_ALL_VALU_MODEL = float(_isa("r04_isa_ntt.json", "ceiling_fr_mul_per_s_all_valu", 1.020e11))
+# scan + 64 of the reduction = 128 per multiplication, each followed by a carry op of the same price; 2400 MHz)
+FR_MUL_MULTIPLIER_CEILING = float(_isa("r04_isa_ntt.json", "ceiling_fr_mul_per_s_multiplier_only", 2.878e11))
+FR_MUL_ALL_VALU_MODEL = float(_isa("r04_isa_ntt.json", "ceiling_fr_mul_per_s_all_valu", 1.113e11))
 
 
 def fr_mont_limbs(x: int) -> np.ndarray:
@@ -402,19 +403,21 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
             "frac": adds / MIXED_ADD_MULTIPLIER_CEILING, "traffic": traffic,
             "peak_source": "instruction count: 3081 v_mad_u64_u32 per mixed addition on the loop's steady-state path "
                            "(profiles/r04_isa_msm_accum.json) x 4.27 cycles per v_mad_u64_u32 and SIMD at saturation (s_memtime, "
-                           "occupancy sweep: profiles/r04_ubench4_pricing.txt) at 2061 MHz x 1024 SIMDs x 64 lanes -- multiplier "
-                           "instructions only; reproducible by hand from that one file",
+                           "occupancy sweep: profiles/r04_ubench4_pricing.txt) at the 2400 MHz maximum clock x 1024 SIMDs x 64 lanes "
+                           "-- multiplier instructions only; reproducible by hand from that one file",
             "all_valu_model": {"peak": MIXED_ADD_ALL_VALU_MODEL, "frac": adds / MIXED_ADD_ALL_VALU_MODEL,
                                "note": "all 4818 VALU instructions of the path priced by class (2.20 / 4.12 / 4.27 cycles): "
-                                       "18.7 k cycles per wavefront and addition; the whole-addition micro-kernel measures 19.5 k"},
+                                       "18.7 k cycles per wavefront and addition at 2400 MHz; the kernel holds 2.06-2.2 GHz "
+                                       "(power-limited) and the whole-addition micro-kernel measures 19.5 k cycles"},
             "kernel_ms": t_acc * 1e3, "launches_per_msm": launches, "terms_per_launch": terms_per_launch,
             "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "algorithmic_bytes": alg_bytes, "traffic": traffic,
                     "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, "
                                       "bytes per launch)"},
             "hbm_frac": ach / HBM_PEAK_GBS,
-            "sq_valu_util": _isa("r03_pmc_sq_valu_msm.json", "ty::msm_accum_kernel grid=524288", {}).get("valu_util"),
-            "note": "integer-VALU-bound (91 % of the issue slots at 2.17 GHz, profiles/r03_pmc_sq_valu_msm.json); the HBM "
+            "sq_valu_util": _isa("r04_pmc_sq_valu_msm.json", "ty::msm_accum_kernel grid=524288", {}).get("valu_util"),
+            "effective_clock_ghz": _isa("r04_pmc_sq_valu_msm.json", "ty::msm_accum_kernel grid=524288", {}).get("effective_clock_ghz"),
+            "note": "integer-VALU-bound (92 % of the issue slots at an effective 2.2 GHz, profiles/r04_pmc_sq_valu_msm.json); the HBM "
                     "fraction the north-star asks for is kept as hbm_frac; PMC traffic is "
                     + (f"{traffic / alg_bytes:.1f}" if traffic else "~19.5") + " x the algorithmic bytes (13 window gathers of a "
                     "128-B-stride record each + bucket store / reload, served by the Infinity Cache) -- see DESIGN.md section 4"}
@@ -480,7 +483,7 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
                               "frac": fr_muls / kern_s / FR_MUL_MULTIPLIER_CEILING,
                               "fr_mul_per_transform": fr_muls,
                               "peak_source": "128 v_mad_u64_u32 per Fr multiplication (profiles/r04_isa_ntt.json) x 4.27 cycles at "
-                                             "2.2 GHz x 1024 SIMDs x 64 lanes (multiplier instructions only)",
+                                             "2400 MHz x 1024 SIMDs x 64 lanes (multiplier instructions only)",
                               "all_valu_model": {"peak": FR_MUL_ALL_VALU_MODEL, "frac": fr_muls / kern_s / FR_MUL_ALL_VALU_MODEL,
                                                  "note": "all 1455 VALU instructions of a radix-4 group (4 multiplications, 8 "
                                                          "additions / subtractions, addressing) priced with their own issue times"},
