@@ -157,6 +157,12 @@ int typlonk_msm_g1_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* c
  *   inverse = 0: data[k] <- sum_i data[i] * (g*omega^k)^i                (fft / coset_fft)
  *   inverse = 1: data[i] <- g^-i * n^-1 * sum_k data[k] * omega^(-ik)    (ifft / coset_ifft)
  * coset_shift: NULL (g = 1) or 4 limbs (Montgomery).  The caller zero-pads to 2^log_n.
+ * Sizes: every log_n <= 32 is accepted (the reference's domain constructor fails above the two-adicity, builder.rs:70);
+ * the parity suite compares whole vectors with the CPU restatement up to 2^27 (a 4-GiB vector); one-multiplication
+ * twiddle tables are kept up to 2^24 points, larger transforms compose their twiddles from two-level tables.
+ * Tables keyed by a caller-chosen coset shift are a cache (8 groups / 3 GiB): building a ninth evicts the least recently
+ * used group after a hipDeviceSynchronize() -- a device-wide wait, so a caller that cycles through many shifts stalls
+ * every stream of the device at each eviction (the prover uses one shift, which stays resident).
  * typlonk_ntt_fr blocks until the result is back on the host; the _dev / _devptr forms (and
  * typlonk_quotient_dev) are stream-ordered on the context's stream and return once enqueued -- any
  * later call on the same context, a typlonk_buf_download or typlonk_sync observes the result. */
@@ -178,6 +184,9 @@ int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int in
  * the three commitments of SlicedPoly<3> are MSMs of [0,n), [n,2n), [2n,3n)), the rest is zero.
  * The schoolbook products of the reference are replaced by a 4n coset NTT: identical result
  * whenever the constraint numerator vanishes on the domain (every valid witness). */
+/* The prover-side entry points (quotient, grand product, open, the rounds, typlonk_prove) take 1 <= log_n <= 22 -- the
+ * sizes the parity suite covers (BASELINE config 5 is 2^22 rows); larger domains return TYPLONK_ERR_DOMAIN / _LENGTH. */
+#define TYPLONK_MAX_PROVER_LOG_N 22
 typedef struct typlonk_quotient_args {
     const typlonk_buf* wires[3];
     const typlonk_buf* z;

@@ -35,7 +35,7 @@ int quotient_extend(typlonk_ctx* ctx, Fr* e, const Fr* src, const Fr* fill, uint
 int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5], const typlonk_buf* const sigma[3],
                          uint32_t log_n, uint32_t* circuit_id) {
     if (!ctx || !selectors || !sigma || !circuit_id) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
-    if (log_n < 1 || log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 30");
+    if (log_n < 1 || log_n > TYPLONK_MAX_PROVER_LOG_N) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 22");
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n, n4 = 4 * n;
     const typlonk_buf* in[8] = {selectors[0], selectors[1], selectors[2], selectors[3], selectors[4],
@@ -99,7 +99,7 @@ int typlonk_quotient_dev(typlonk_ctx* ctx, const typlonk_quotient_args* args, ui
 
 namespace {
 int quotient_run(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t log_n, typlonk_buf* t_out, uint32_t extended) {
-    if (log_n < 1 || log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 30");
+    if (log_n < 1 || log_n > TYPLONK_MAX_PROVER_LOG_N) return fail(ctx, TYPLONK_ERR_DOMAIN, "quotient needs 1 <= log_n <= 22");
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n, n4 = 4 * n;
     const uint32_t log4 = log_n + 2;
@@ -189,7 +189,7 @@ int typlonk_grand_product_dev(typlonk_ctx* ctx, const typlonk_buf* const wires[3
                               uint32_t log_n, typlonk_buf* z_evals_out) {
     if (!ctx || !wires || !sigma || !beta || !gamma || !cosets || !z_evals_out)
         return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
-    if (log_n > 30) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 30");
+    if (log_n > TYPLONK_MAX_PROVER_LOG_N) return fail(ctx, TYPLONK_ERR_DOMAIN, "grand product needs log_n <= 22");
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = 1ull << log_n;
     for (int i = 0; i < 3; ++i)
