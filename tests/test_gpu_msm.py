@@ -500,3 +500,28 @@ def test_chunked_pipeline_gives_identical_results(built, chunks, monkeypatch):
                 assert (fxy == exp_xy).all() and finf == exp_inf, (chunks, m, kind, "shard")
     finally:
         c2.close()
+
+
+def test_more_than_2_23_terms_takes_the_counting_sort_fallback(ctx):
+    """The segmented sort indexes terms with 23 bits; a longer MSM falls back to the global counting sort (msm_host.hip
+    msm_enqueue -- the path has no switch of its own since round 4, so this is the test that reaches it): 2^23 + 5 terms
+    over [s^i]G against commit(p) == [p(s)]G (kzg/src/lib.rs:102-105), with the ragged lengths m - 1 and m - 3, and a
+    chunk-sized control below the limit through the ordinary path over the same SRS."""
+    import torch
+    from oracle import coracle as CO
+
+    m = (1 << 23) + 5
+    s_limbs = np.array(O.fr_to_mont_limbs(2), dtype=np.uint64)
+    sid = ctx.srs_generate(s_limbs, m)
+    rng = np.random.default_rng(823)
+    sc = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    buf = ctx.alloc(m)
+    buf.upload(sc)
+    for mm in (m, m - 1, m - 3, (1 << 23) - 1):
+        exp_xy, exp_inf = CO.g1_mul_generator(CO.poly_eval(sc[:mm], s_limbs))
+        got, ginf = ctx.msm_devptr(sid, buf.devptr, mm)
+        assert (got == exp_xy).all() and ginf == exp_inf, mm
+    buf.free()
+    ctx.srs_free(sid)
+    torch.cuda.empty_cache()
