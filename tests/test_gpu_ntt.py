@@ -142,7 +142,8 @@ def test_full_size_vs_c_oracle(ctx, log_n):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_both_butterfly_kernels_give_the_c_oracles_words(built, mode, monkeypatch):
     """The NTT has two pass kernels: 8 x 32-bit words (ff.hpp) and nine 30-bit limbs with twiddles in the 2^270 domain
-    (fr30.hpp; the default up to 2^19).  TYPLONK_NTT_FR30 = 0 / 1 / 2 selects neither / up to 2^19 / every size; each
+    (fr30.hpp; since round 4 the default wherever its full twiddle tables exist, i.e. up to 2^24 points).
+    TYPLONK_NTT_FR30 = 0 / 1 / 2 selects the 8 x 32 kernel everywhere / the default policy / the 30-bit kernel everywhere; each
     mode must reproduce the C restatement of ark-poly's radix-2 FFT word for word -- forward, inverse (n^-1), coset and
     inverse coset, one to three passes, the extremes of the input range (0, r - 1) included."""
     import typlonk_amd

@@ -126,6 +126,28 @@ __device__ __forceinline__ Fr fr30_to_canonical(const Fr30& a) {
     fe_reduce_once(o);
     return o;
 }
+// x - q r for a small q (< 2^14), limb-wise with a signed running carry; exact limbs out.  Needs x >= q r.
+__device__ __forceinline__ Fr30 fr30_sub_qr(const Fr30& x, uint32_t q) {
+    Fr30 o;
+    int64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        acc += (int64_t)x.v[i] - (int64_t)((uint64_t)q * fr30_r(i));
+        o.v[i] = (uint32_t)acc & FR30_MASK;
+        acc >>= 30;   // arithmetic: the borrow travels as a negative carry
+    }
+    return o;
+}
+// Lazy value -- limbs 0..7 <= 2^30 + 3, limb 8 < 2^29, the contract of every fr30_mul operand -- -> exact limbs,
+// value < 2 r, WITHOUT a multiplication: one quotient estimate from the top limb.  r = 0x73ed * 2^240 + (< 2^240), so
+// q = floor(x_8 / (0x73ed + 1)) satisfies q r < x_8 2^240 <= x (the subtraction cannot go negative), and the true
+// quotient Q = floor(x / r) < (x_8 + 1 + 2^-27) / 0x73ed exceeds it by less than x_8 / (0x73ed * 0x73ee) + 1 + 2^-14
+// < 2^29 / 2^29.71 + 1.0001 < 1.62, i.e. by at most 1: x - q r < 2 r.  ~120 cycles of VALU issue against ~860 for
+// fr30_mul by 2^270 mod r (ntt_pass30_kernel: the last pass of a forward transform has no factor to fold the reduction into).
+__device__ __forceinline__ Fr30 fr30_reduce_lazy(const Fr30& x) {
+    constexpr uint32_t R8P1 = 0x73edu + 1u;
+    return fr30_sub_qr(x, x.v[8] / R8P1);
+}
 __device__ __forceinline__ Fr30 fr30_const_one() {
     Fr30 r;
 #pragma unroll

@@ -162,8 +162,8 @@ struct typlonk_ctx {
     // (direction, size, shift) groups / bytes stay resident, the least recently used group is dropped first
     static constexpr size_t COSET_GROUPS_MAX = 8;
     static constexpr size_t COSET_BYTES_MAX = (size_t)3 << 30;
-    int ntt_fr30 = 1;              // 0 = off, 1 = 9 x 30-bit butterflies (fr30.hpp) up to 2^20 and for every inverse transform,
-                                   // 2 = for every transform (the 4096-element tiles of 2^20 are then not used)
+    int ntt_fr30 = 1;              // 0 = the 8 x 32-bit kernel everywhere, 1 = the default policy (9 x 30-bit butterflies, fr30.hpp, for
+                                   // every inverse transform and for forward ones up to 2^NTT_FR30_FWD_MAX_LOG), 2 = 30-bit everywhere
     // profiling
     bool profiling = false;
     std::vector<tyh::ProfStage> prof;
@@ -178,6 +178,9 @@ namespace tyh {
 constexpr uint32_t MSM_CAP_MIN = 32;
 // full (one-multiplication) twiddle / coset tables are built up to this many entries (512 MB); above, two-level tables
 constexpr uint32_t NTT_FULL_MAX_LOG = 24;
+// default policy (TYPLONK_NTT_FR30 = 1): forward transforms take the 9 x 30-bit kernel up to this size, inverse ones always
+// (their closing factor is free); set from the same-box A/B of the two kernels (ntt_host.hip, ntt_run)
+constexpr uint32_t NTT_FR30_FWD_MAX_LOG = 32;
 
 int fail(typlonk_ctx* c, int code, const std::string& msg);
 

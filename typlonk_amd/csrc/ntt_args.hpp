@@ -17,6 +17,7 @@ struct NttPassArgs {
     uint64_t N1, Q, N2, N3, out_stride;
     uint64_t n_valid;  // input elements at index >= n_valid are taken as zero and not read (zero-padded transforms); ~0: all
     const Fr* sub_tw;  // w_M^e, e < M/2
+    const uint32_t* sub_tw30;  // the 9 x 30-bit kernel: 2^14 w_M^e as nine limbs on a 12-word stride (global memory)
     const Fr* tw_lo;   // w_{row_len}^e,          e < 2^tw_h
     const Fr* tw_hi;   // w_{row_len}^(e * 2^tw_h)
     const Fr* pre_lo;  // coset powers g^i applied to the input of pass 1 (forward coset NTT)

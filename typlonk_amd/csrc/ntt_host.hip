@@ -83,6 +83,30 @@ int get_pow_table(typlonk_ctx* ctx, const std::string& key, const Fr& base, cons
     return upload_table(ctx, key, h, out);
 }
 
+// powers table of the 9 x 30-bit kernel: out[j] = scale * base^j re-cut into nine 30-bit limbs on a 12-word (48-byte)
+// stride -- what NttArith30::ldtw (ntt_kernels.hip) reads from global memory
+int get_pow_table30(typlonk_ctx* ctx, const std::string& key, const Fr& base, const Fr& scale, size_t n, Table* out) {
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        it->second.last_use = ++ctx->table_tick;
+        *out = it->second;
+        return TYPLONK_OK;
+    }
+    std::vector<Fr> h((12 * n + 7) / 8, Fr::zero());
+    uint32_t* w = reinterpret_cast<uint32_t*>(h.data());
+    Fr x = scale;
+    for (size_t j = 0; j < n; ++j) {
+        for (int i = 0; i < 9; ++i) {   // fr30_unpack (fr30.hpp) on the host
+            const int bit = 30 * i, wi = bit >> 5, sh = bit & 31;
+            uint32_t t = x.v[wi] >> sh;
+            if (sh > 2 && wi + 1 < 8) t |= x.v[wi + 1] << (32 - sh);
+            w[12 * j + i] = t & 0x3fffffffu;
+        }
+        x = fe_mul(x, base);
+    }
+    return upload_table(ctx, key, h, out);
+}
+
 // Full one-multiplication table built on the device from a two-level pair (launch_ntt_full_table); kept per
 // context like every other table.  Sizes above 2^NTT_FULL_MAX_LOG entries (2^24 = 512 MB) are not
 // built: *out stays empty and the kernel composes the factor from the two-level tables instead.
@@ -211,8 +235,9 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     // (not inside a prover round: there the 144 KiB workgroups crowd out the LDS of the MSM lanes' sort kernels running
     // beside them -- prove() 38.1 -> 38.3 ms in the same-box A/B)
     // (forward only: an inverse 2^20 transform is 4 % faster in three passes of the 30-bit kernel, 0.148 against 0.153 ms)
-    bool big = log_n == 20 && (!inverse || ctx->ntt_fr30 == 0) && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
-    if (big && ctx->ntt_fr30 == 2) big = false;  // 36 B per element: 4096 of them do not fit
+    // (round 4: the 30-bit kernel reads its sub-transform twiddles from global memory, so 4096 of its 36-byte elements fit
+    // the LDS -- 144 KiB -- and it can take the two-pass form too)
+    const bool big = log_n == 20 && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
     // log2 of the tile capacity: 4096-element tiles in the first pass of the two-pass 2^20 transform (strided: four columns
     // make 128-byte runs) and 2048 in the last (rows are contiguous, and two workgroups per CU overlap each other's
     // load / compute / store phases: 0.0775 -> 0.070 ms, profiles/r03_ntt_2_20_tiles.txt)
@@ -234,8 +259,11 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     // Round 3 (radix-4 groups in both kernels, profiles/r03_ntt_fr30_modes.txt): an INVERSE transform is 4-9 % faster on the
     // 30-bit kernel at every size (its n^-1 / coset factor closes the last pass for free), a forward one from 2^21 on is
     // not; at 2^20 a forward transform takes the two-pass big tiles when they are allowed, the 30-bit kernel otherwise
-    const bool want30 = ctx->ntt_fr30 != 0 && !big &&
-                        (ctx->ntt_fr30 == 2 || log_n <= 20 || inverse);
+    // Round 4 (profiles/r04_ntt_fr30_global_twiddles.txt): with its twiddles in global memory the 30-bit kernel runs four
+    // 1024-element workgroups per CU and takes the two-pass 2^20 form: 2^20 0.141 -> 0.129 ms in both directions, 2^21
+    // forward 0.268 -> 0.252; mode 1 (default) = the 30-bit kernel for every inverse transform and for forward ones up to
+    // 2^NTT_FR30_FWD_MAX_LOG points (host.hpp)
+    const bool want30 = ctx->ntt_fr30 == 2 || (ctx->ntt_fr30 == 1 && (inverse || log_n <= NTT_FR30_FWD_MAX_LOG));
 
     // coset / scaling tables (the full tables of the 8 x 32 kernel are not built when the other kernel will run)
     Table pre_lo{}, pre_hi{}, post_lo{}, post_hi{}, scale{}, pre_full{}, post_full{};
@@ -298,7 +326,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             const uint32_t k = ks[p];
             const uint64_t M = 1ull << k;
             const Fr w = inverse ? fr_domain_root_inv(k) : fr_domain_root(k);
-            if ((rc = get_pow_table(ctx, "sub30:" + dir + ":" + std::to_string(k), w, c14, (size_t)std::max<uint64_t>(M / 2, 1), &sub30[p])))
+            if ((rc = get_pow_table30(ctx, "sub30:" + dir + ":" + std::to_string(k), w, c14, (size_t)std::max<uint64_t>(M / 2, 1), &sub30[p])))
                 return rc;
             if (p + 1 < P) {
                 const uint32_t lrow = ilog2_u64(rl);
@@ -392,7 +420,8 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         const uint64_t E = M << logT;
         const uint64_t blocks = N / E;
         if (f30) {
-            a.sub_tw = sub30[p].d;
+            a.sub_tw = nullptr;
+            a.sub_tw30 = reinterpret_cast<const uint32_t*>(sub30[p].d);
             a.tw_full = tw30[p].d;
             a.tw_lo = a.tw_hi = nullptr;
             a.pre_lo = a.pre_hi = a.post_lo = a.post_hi = nullptr;
@@ -400,7 +429,8 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
             a.post_full = last ? post30.d : nullptr;
             a.scale = last ? scale30.d : nullptr;
         }
-        const size_t lds = (size_t)(E + std::max<uint64_t>(M / 2, 1)) * (f30 ? 36 : sizeof(Fr));
+        // LDS: the tile, and (8 x 32 kernel) the sub-transform's twiddles behind it
+        const size_t lds = f30 ? (size_t)E * 36 : (size_t)(E + std::max<uint64_t>(M / 2, 1)) * sizeof(Fr);
         const unsigned threads = big ? (unsigned)std::max<uint64_t>(E / 4, 64) : 256u;
         {
             static const char* names[4] = {"ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_pass4"};

@@ -48,6 +48,8 @@ __device__ __forceinline__ Fr ntt_pow2l(const Fr* lo, const Fr* hi, uint32_t h, 
 struct NttArith32 {
     using E = Fr;
     using P = Fr*;
+    using TW = Fr*;   // sub-transform twiddles: staged in LDS behind the tile
+    static __device__ __forceinline__ E ldtw(TW tw, uint32_t idx) { return ntt_ld(tw + idx); }
     static __device__ __forceinline__ E ld(P tile, uint32_t idx) { return ntt_ld(tile + idx); }
     static __device__ __forceinline__ void st(P tile, uint32_t idx, const E& x) { ntt_st(tile + idx, x); }
     static __device__ __forceinline__ E add(const E& a, const E& b) { return fe_add(a, b); }
@@ -57,6 +59,19 @@ struct NttArith32 {
 struct NttArith30 {
     using E = Fr30;
     using P = uint32_t*;
+    // sub-transform twiddles: read from GLOBAL memory, nine limbs on a 12-word (48-byte) stride (NttPassArgs::sub_tw30).
+    // At 36 B per element the tile alone fills the LDS budget -- 4096 elements = 144 KiB, four 1024-element tiles = 144 KiB
+    // per CU -- and the table (<= 24 KiB) lives in L1 / L2.
+    using TW = const uint32_t*;
+    static __device__ __forceinline__ E ldtw(TW tw, uint32_t idx) {
+        const uint4* q = reinterpret_cast<const uint4*>(tw + 12 * (size_t)idx);
+        const uint4 a = q[0], b = q[1];
+        E r;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+        r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+        r.v[8] = tw[12 * (size_t)idx + 8];
+        return r;
+    }
     static __device__ __forceinline__ E ld(P tile, uint32_t idx) {
         E r;
 #pragma unroll
@@ -78,7 +93,7 @@ struct NttArith30 {
 // copy into LDS, the copy out of it and two barriers per pass disappear.  i_fast: in the first group consecutive lanes
 // take consecutive i instead of consecutive t (the last pass reads rows of M contiguous elements).
 template <class A, class LoadG, class StoreG>
-__device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A::P stw, uint32_t k, uint32_t logT, uint32_t E,
+__device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A::TW stw, uint32_t k, uint32_t logT, uint32_t E,
                                                   uint32_t tid, uint32_t nt, bool direct, bool i_fast, LoadG gload, StoreG gstore) {
     using El = typename A::E;
     const uint32_t T = 1u << logT;
@@ -94,7 +109,7 @@ __device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A
             const El x = first ? gload(pos, t) : A::ld(tile, ia), y = first ? gload(pos + half, t) : A::ld(tile, ib);
             A::st(tile, ia, A::add(x, y));
             const El d = A::sub(x, y);
-            A::st(tile, ib, lh == 0 ? d : A::mul(d, A::ld(stw, pos)));
+            A::st(tile, ib, lh == 0 ? d : A::mul(d, A::ldtw(stw, pos)));
         }
         __syncthreads();
         s = 1;
@@ -118,14 +133,14 @@ __device__ __forceinline__ void ntt_stages_radix4(typename A::P tile, typename A
             const El s0 = A::add(x0, x2), s1 = A::add(x1, x3);
             El d0 = A::sub(x0, x2), d1 = A::sub(x1, x3);
             if (!lastg) {
-                d0 = A::mul(d0, A::ld(stw, low << s));
-                d1 = A::mul(d1, A::ld(stw, (low + quarter) << s));
+                d0 = A::mul(d0, A::ldtw(stw, low << s));
+                d1 = A::mul(d1, A::ldtw(stw, (low + quarter) << s));
             } else {
-                d1 = A::mul(d1, A::ld(stw, 1u << s));   // w^(M/4); d0's twiddle is 1
+                d1 = A::mul(d1, A::ldtw(stw, 1u << s));   // w^(M/4); d0's twiddle is 1
             }
             El y1 = A::sub(s0, s1), y3 = A::sub(d0, d1);
             if (!lastg) {
-                const El tw = A::ld(stw, low << (s + 1));
+                const El tw = A::ldtw(stw, low << (s + 1));
                 y1 = A::mul(y1, tw);
                 y3 = A::mul(y3, tw);
             }
@@ -222,9 +237,9 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
 }
 
 // ---- the same pass on 9 x 30-bit limbs (fr30.hpp) -------------------------------------------------------------------
-// Same tiling, addressing and stage order as ntt_pass_kernel.  The LDS tile holds 9 words per element; every table
-// (sub_tw, tw_full, pre_full, post_full, scale) is in the 2^270 domain and must be a full table (ntt_host.hip selects this
-// kernel only then).  Additions are lazy (fr30.hpp states the bounds); a pass ends with a multiplication of every
+// Same tiling, addressing and stage order as ntt_pass_kernel.  The LDS tile holds 9 words per element and nothing else
+// (the sub-transform twiddles are read from global memory: sub_tw30); every table (sub_tw30, tw_full, pre_full, post_full,
+// scale) is in the 2^270 domain and must be a full table (ntt_host.hip selects this kernel only then).  Additions are lazy (fr30.hpp states the bounds); a pass ends with a multiplication of every
 // element -- the inter-pass twiddle, the coset / scaling factor of the last pass, or 2^270 mod r when the last pass has
 // no factor -- which brings it below 2r; the last pass then subtracts r once more where needed, so that what reaches
 // the caller is the canonical residue, bit for bit what ntt_pass_kernel writes.
@@ -244,11 +259,9 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     const uint32_t k = a.k, logT = a.logT;
     const uint32_t M = 1u << k, T = 1u << logT, E = M << logT;
     uint32_t* tile = reinterpret_cast<uint32_t*>(ntt_smem);
-    uint32_t* stw = tile + 9 * E;
+    const uint32_t* stw = a.sub_tw30;   // global memory (NttArith30::ldtw)
     const uint32_t tid = threadIdx.x;
     const uint64_t b = blockIdx.x;
-
-    for (uint32_t i = tid; i < (M >> 1); i += NTT_THREADS) lds_st30(stw + 9 * i, fr30_unpack(ntt_ld(a.sub_tw + i)));
 
     uint64_t base = 0, c0 = 0, q = 0, k1base = 0, obase = 0;
     if (!a.last) {
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
             const uint64_t o = obase + t + a.out_stride * kk;
             if (a.post_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.post_full + o)));
             else if (a.scale) x = fr30_mul(x, fr30_unpack(ntt_ld(a.scale)));
-            else x = fr30_mul(x, fr30_const_one());
+            else x = fr30_reduce_lazy(x);   // no factor to fold the reduction into: two quotient estimates instead of a multiplication
             ntt_st(a.out + o, fr30_to_canonical(x));
         }
     };
