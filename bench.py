@@ -63,10 +63,11 @@ def _isa(name: str, key: str, default):
 
 MIXED_ADD_MULTIPLIER_CEILING = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_multiplier_only", 11.956e9))
 MIXED_ADD_ALL_VALU_MODEL = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_all_valu", 8.398e9))
-# the same for one Fr multiplication inside the NTT butterflies (profiles/r04_isa_ntt.json: 64 v_mad_u64_u32 of the product
-# scan + 64 of the reduction = 128 per multiplication, each followed by a carry op of the same price; 2400 MHz)
-FR_MUL_MULTIPLIER_CEILING = float(_isa("r04_isa_ntt.json", "ceiling_fr_mul_per_s_multiplier_only", 2.878e11))
-FR_MUL_ALL_VALU_MODEL = float(_isa("r04_isa_ntt.json", "ceiling_fr_mul_per_s_all_valu", 1.113e11))
+# the same for one Fr multiplication inside the NTT butterflies.  Since round 4 the default kernel is the one on nine 30-bit
+# limbs (profiles/r04_isa_ntt30.json: 153.75 v_mad_u64_u32 per multiplication, 1155 VALU instructions per radix-4 group of
+# four multiplications = 4156 cycles; the 8 x 32 kernel, profiles/r04_isa_ntt.json: 128 + a carry op each, 5655 cycles)
+FR_MUL_MULTIPLIER_CEILING = float(_isa("r04_isa_ntt30.json", "ceiling_fr_mul_per_s_multiplier_only", 2.396e11))
+FR_MUL_ALL_VALU_MODEL = float(_isa("r04_isa_ntt30.json", "ceiling_fr_mul_per_s_all_valu", 1.514e11))
 
 
 def fr_mont_limbs(x: int) -> np.ndarray:
@@ -461,8 +462,8 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
     for _ in range(2):
         ctx.ntt_devptr(v.data_ptr(), log_n)
     torch.cuda.synchronize()
-    # forward and inverse transforms alternate (a round trip leaves the data unchanged); they run on different kernels
-    # from 2^20 up (ntt_host.hip ntt_run: forward on 8 x 32-bit words, inverse on 9 x 30-bit limbs), so both are reported
+    # forward and inverse transforms alternate (a round trip leaves the data unchanged); both run on the 9 x 30-bit kernel
+    # since round 4 (ntt_host.hip ntt_run), the inverse one with its n^-1 factor folded into the last pass
     reps, kdir = 10, [0.0, 0.0]
     t1 = time.perf_counter()
     for i in range(reps):
@@ -474,7 +475,7 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
     kern_s = kdir[0] / (reps // 2) * 1e-3     # the VALU figures below describe the forward kernel (profiles/r03_isa_ntt.json)
     # Fr multiplications the kernels execute per transform: n/2 log2(n) butterflies less the
     # twiddle-1 ones of the last two stages of every pass, plus one inter-pass / scaling factor per element and pass
-    fr_muls = _isa("r04_isa_ntt.json", f"fr_mul_per_transform_2_{log_n}", n * (log_n / 2.0 + 1))
+    fr_muls = _isa("r04_isa_ntt30.json", f"fr_mul_per_transform_2_{log_n}", n * (log_n / 2.0 + 1))
     mean_s = kern / reps * 1e-3
     result["ntt"] = {"log_n": log_n, "ms": tn * 1e3, "kernel_ms": kern / reps,
                      "forward_kernel_ms": kdir[0] / (reps // 2), "inverse_kernel_ms": kdir[1] / (reps // 2),
@@ -482,20 +483,22 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
                      "valu": {"achieved": fr_muls / kern_s, "peak": FR_MUL_MULTIPLIER_CEILING, "unit": "Fr mul/s",
                               "frac": fr_muls / kern_s / FR_MUL_MULTIPLIER_CEILING,
                               "fr_mul_per_transform": fr_muls,
-                              "peak_source": "128 v_mad_u64_u32 per Fr multiplication (profiles/r04_isa_ntt.json) x 4.27 cycles at "
-                                             "2400 MHz x 1024 SIMDs x 64 lanes (multiplier instructions only)",
+                              "peak_source": "153.75 v_mad_u64_u32 per Fr multiplication on nine 30-bit limbs (profiles/r04_isa_ntt30.json) "
+                                             "x 4.27 cycles at 2400 MHz x 1024 SIMDs x 64 lanes (multiplier instructions only)",
                               "all_valu_model": {"peak": FR_MUL_ALL_VALU_MODEL, "frac": fr_muls / kern_s / FR_MUL_ALL_VALU_MODEL,
-                                                 "note": "all 1455 VALU instructions of a radix-4 group (4 multiplications, 8 "
-                                                         "additions / subtractions, addressing) priced with their own issue times"},
-                              "sq_valu_util": _isa("r03_pmc_sq_valu_ntt.json", "ty::ntt_pass_kernel grid=%d" % (n // 4), {}).get("valu_util")}}
-    for name in ("r03_pmc_ntt.json", "r02_pmc_ntt.json"):   # PMC traffic of one pass
-        pm = _isa(name, f"ntt_pass_kernel n=2^{log_n}", None)
+                                                 "note": "all 1155 VALU instructions of a radix-4 group (4 multiplications, 8 lazy "
+                                                         "additions / subtractions, addressing) priced by class: 4156 cycles"},
+                              "sq_valu_util": _isa("r04_pmc_sq_valu_ntt.json", "ty::ntt_pass30_kernel grid=%d" % (n // 4), {}).get("valu_util")}}
+    # PMC traffic of one pass (the 30-bit kernel since round 4; the older files describe the 8 x 32 kernel)
+    for name, key in (("r04_pmc_ntt.json", f"ntt_pass30_kernel n=2^{log_n}"), ("r03_pmc_ntt.json", f"ntt_pass_kernel n=2^{log_n}")):
+        pm = _isa(name, key, None)
         if pm:
             result["ntt"]["pmc_traffic_bytes_per_pass"] = pm["traffic_bytes_per_pass"]
-            result["ntt"]["pmc_source"] = "profiles/" + name
+            result["ntt"]["pmc_source"] = f"profiles/{name} ({key})"
             break
-    result["ntt"]["note"] = ("VALU-bound (80 % Fr multiplications, DESIGN.md section 5): the algorithmic figure counts 64 B per "
-                             "element once; the passes of a transform move more (pmc_traffic_bytes_per_pass x passes)")
+    result["ntt"]["note"] = ("VALU-bound arithmetic with exposed memory phases at this size (DESIGN.md section 5): the algorithmic "
+                             "figure counts 64 B per element once; the passes of a transform move more "
+                             "(pmc_traffic_bytes_per_pass x passes: data in, data out and a full twiddle table)")
 
 
 def bench_prove_sequence(ctx, sh, n, log_n, device, result) -> None:
