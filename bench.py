@@ -494,6 +494,9 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
         pm = _isa(name, key, None)
         if pm:
             result["ntt"]["pmc_traffic_bytes_per_pass"] = pm["traffic_bytes_per_pass"]
+            other = _isa(name, key + " wg1024", None)   # the two passes of the 2^20 transform run different workgroup sizes
+            if other:
+                result["ntt"]["pmc_traffic_bytes_per_transform"] = pm["traffic_bytes_per_pass"] + other["traffic_bytes_per_pass"]
             result["ntt"]["pmc_source"] = f"profiles/{name} ({key})"
             break
     result["ntt"]["note"] = ("VALU-bound arithmetic with exposed memory phases at this size (DESIGN.md section 5): the algorithmic "
