@@ -34,6 +34,7 @@ int main() {
     uint64_t xy[12] = {0};
     uint8_t inf = 1;
     REQUIRE(typlonk_comm_fold_g1(ctx, xy, &inf, 1) == TYPLONK_ERR_INVALID_ARG);   // no communicator yet
+    REQUIRE(typlonk_comm_available() == 1);                                        // librccl loads here (not collective)
     uint8_t id[TYPLONK_COMM_ID_BYTES];
     REQUIRE(typlonk_comm_unique_id(id) == TYPLONK_OK);
     OK(typlonk_comm_init(ctx, id, 0, 1));

@@ -153,7 +153,7 @@ def test_native_rccl_exchange_behind_the_c_abi(built):
         assert e.value.code == ERR_LENGTH
         again = ctx.msm_sharded_devptr(shard, buf.devptr, n)
         assert (again[0] == b[0]).all() and again[1] == b[1]
-        pts = [a, loc, (np.zeros(12, dtype=np.uint64), 1)] * 7        # 21 points: more than the first reservation
+        pts = [a, loc, (np.zeros(12, dtype=np.uint64), 1)] * 24       # 72 points: three pieces of the 32-record exchange buffers
         back = ctx.comm_fold(pts)
         for (x, i), (y, j) in zip(pts, back):
             assert i == j and (j == 1 or (x == y).all())
