@@ -12,7 +12,7 @@ namespace tyh {
 void msm_shape(size_t m, uint32_t* c_out, uint32_t* w_out) {
     uint32_t lg = 0;  // ceil(log2 m)
     while (((size_t)1 << lg) < m) ++lg;
-    // measured on MI355X (tools/sweep_c.py): the best window is c ~ ceil(log2 m) clamped to [8, 16];
+    // measured on MI355X in round 1 (a sweep over forced windows): the best window is c ~ ceil(log2 m) clamped to [8, 16];
     // the bucket reduction is a fixed ~50-operation dependent chain whatever c is, so small MSMs want
     // many small buckets (short accumulate chains) rather than few windows
     int c = (int)lg;
