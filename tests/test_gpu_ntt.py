@@ -182,3 +182,55 @@ def test_beyond_the_full_table_limit_vs_c_oracle(ctx, log_n):
     f = ctx.ntt(x, log_n)
     assert (f == CO.ntt(x, log_n, threads=0)).all()
     assert (ctx.ntt(f, log_n, inverse=True) == x).all()
+
+
+def test_the_two_kernels_agree_on_inputs_that_stretch_the_lazy_bounds(built, monkeypatch):
+    """The 30-bit kernel keeps values lazily reduced through a pass (sums double, differences carry a bias of 2^12 r) and
+    closes a forward transform with fr30_reduce_lazy, one quotient estimate from the top limb (fr30.hpp).  Inputs built
+    to push those values as far as they go -- all r - 1, alternating r - 1 / 0 / 1 at every stride, half-and-half blocks,
+    a single r - 1 in a field of zeros, ramps -- must give the words the 8 x 32 kernel gives, forward, coset-forward and
+    inverse, at every pass structure (one to three passes, the two-pass 2^20 form, odd and even stage counts)."""
+    import typlonk_amd
+
+    rm1 = np.array(O.fr_to_mont_limbs(O.R - 1), dtype=np.uint64)
+    one = np.array(O.fr_to_mont_limbs(1), dtype=np.uint64)
+    g = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
+
+    def patterns(n):
+        idx = np.arange(n)
+        out = [np.tile(rm1, (n, 1))]
+        for stride in (1, 2, 4, max(1, n // 4), max(1, n // 2)):
+            for other in (np.zeros(4, dtype=np.uint64), one):
+                x = np.tile(rm1, (n, 1))
+                x[(idx // stride) % 2 == 1] = other
+                out.append(x)
+        x = np.zeros((n, 4), dtype=np.uint64)
+        x[n // 3] = rm1
+        out.append(x)
+        ramp = np.zeros((n, 4), dtype=np.uint64)
+        ramp[:, 0] = idx.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF) % np.uint64(1 << 62)
+        ramp[:, 3] = np.uint64(0x3FFFFFFFFFFFFFFF)          # just below 2^254
+        out.append(ramp)
+        return out
+
+    res = {}
+    for mode in (0, 2):
+        monkeypatch.setenv("TYPLONK_NTT_FR30", str(mode))
+        c2 = typlonk_amd.Context(0)
+        try:
+            for log_n in (3, 8, 10, 11, 13, 16, 17, 19, 20, 21):
+                for k, x in enumerate(patterns(1 << log_n)):
+                    res[(mode, log_n, k, "f")] = c2.ntt(x, log_n)
+                    res[(mode, log_n, k, "c")] = c2.ntt(x, log_n, coset=g)
+                    res[(mode, log_n, k, "i")] = c2.ntt(x, log_n, inverse=True)
+        finally:
+            c2.close()
+    for (mode, log_n, k, d), v in res.items():
+        if mode == 0:
+            assert (v == res[(2, log_n, k, d)]).all(), (log_n, k, d)
+    # and one of them against the CPU restatement, so that the agreement is not two kernels sharing a mistake
+    from oracle import coracle as CO
+
+    for log_n in (10, 16):
+        x = patterns(1 << log_n)[0]
+        assert (res[(2, log_n, 0, "f")] == CO.ntt(x, log_n)).all()
