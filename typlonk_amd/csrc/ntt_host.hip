@@ -133,6 +133,9 @@ int get_full_table(typlonk_ctx* ctx, const std::string& key, const Table& lo, co
         DevGuard g;
         g.add(t.d);
         HIPCHK(hipGetLastError());
+        // built once per context: complete before it enters the cache, so that a later lookup from another stream
+        // (typlonk_set_stream, the prover's extension lane) needs no ordering against the build
+        HIPCHK(hipStreamSynchronize(ctx->stream));
         g.dismiss();
     }
     ctx->tables[key] = t;
