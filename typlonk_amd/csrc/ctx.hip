@@ -95,7 +95,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         ctx->msm_rc4 = (strcmp(e, "rc4") == 0);
         ctx->msm_rc2_force = (strcmp(e, "rc2") == 0);
     }
-    if (const char* e = getenv("TYPLONK_MSM_CHAIN")) ctx->msm_chain = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_MSM_CHAIN")) ctx->msm_chain = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
         const int l = atoi(e);
         if (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) ctx->msm_lanes = l;

@@ -81,6 +81,8 @@ struct SortBufs {
     }
 };
 constexpr int MSM_MAX_CHUNKS = 8;
+constexpr size_t MSM_CHAIN_MIN_TERMS = (size_t)1 << 17;   // typlonk_ctx::msm_chain
+constexpr size_t MSM_FOUR_LANES_BELOW = (size_t)1 << 17;  // typlonk_ctx::msm_inflight
 
 struct MsmWs {
     SortBufs sb[2];
@@ -115,8 +117,8 @@ struct typlonk_buf {
 };
 
 // Environment switches read by typlonk_init (the ones the parity tests parametrise; every combination gives the same bits):
-//   TYPLONK_MSM_INFLIGHT  MSMs of a batch in flight at once (1..4, default 3)
-//   TYPLONK_MSM_CHAIN     0: the lanes of a batch run free instead of chaining their accumulations
+//   TYPLONK_MSM_INFLIGHT  MSMs of a batch in flight at once (1..4; default: by SRS length, MsmQueue)
+//   TYPLONK_MSM_CHAIN     0 | 1: the lanes of a batch run free / chain their accumulations (default: by term count)
 //   TYPLONK_MSM_CHUNKS    chunks of a stand-alone MSM (0 = by length)
 //   TYPLONK_MSM_LANES     lanes per bucket of the accumulation (1, 2, 4, 8, 16; 0 = by bucket load)
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
@@ -136,8 +138,9 @@ struct typlonk_ctx {
     static constexpr int MSM_LANES = 4;
     tyh::MsmWs ws[MSM_LANES];
     hipStream_t lane[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // lanes 1.. of typlonk_msm_g1_batch* (lane 0 = stream)
-    int msm_inflight = 3;           // MSMs of a batch in flight at once (1..MSM_LANES); with the accumulations chained, a fourth
-                                    // lane only adds a sort competing for the same slots (profiles/r03_msm_chain_ab.txt)
+    int msm_inflight = 0;           // MSMs of a batch in flight at once (1..MSM_LANES; 0 = by SRS length: 3, where the
+                                    // accumulations are chained and a fourth lane only adds a sort competing for the same
+                                    // slots (profiles/r03_msm_chain_ab.txt), 4 below 2^17 points, where they run free)
     hipEvent_t lane_evt[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // "scalars ready" marks (MsmQueue::submit)
     hipEvent_t batch_fence = nullptr;   // typlonk_msm_g1_batch_devptr: everything queued before the call (MsmQueue::fence)
     // Queued MSMs (a batch, a prover round) run their accumulations ONE AFTER THE OTHER, whichever lanes they are on: the
@@ -147,7 +150,12 @@ struct typlonk_ctx {
     // nothing overlaps (profiles/r03_msm_batch_timeline_before.txt).
     hipEvent_t accum_chain = nullptr;
     bool accum_chain_live = false;
-    bool msm_chain = true;
+    // A short accumulation does NOT fill the chip: below 2^17 terms the lanes run free (profiles/r04_ab_chain_by_size.txt:
+    // prove() at 2^16 5.75 -> 5.09 ms, 2^14 4.18 -> 3.41, 2^12 3.24 -> 3.05).  Free lanes also win inside a 2^17 / 2^18
+    // proof (7.4 -> 7.2, 11.8 -> 11.4 ms) but lose in a pure batch of nine 2^17-term MSMs -- an 8-way shard's round,
+    // 0.419 -> 0.464 ms per MSM -- so the switch sits below the shard size; from 2^19 on the chain is never worse and
+    // 2^20 needs it.  -1 = by term count (MSM_CHAIN_MIN_TERMS), 0 / 1 = TYPLONK_MSM_CHAIN.
+    int msm_chain = -1;
     int msm_chunks = 0;            // chunks of a stand-alone MSM (0 = choose by length)
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_rc4 = false;          // always the four-launch row/column reduction

@@ -227,7 +227,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             // two size classes (the larger half of the buckets: `lanes`, the smaller half: lanes / 2) when lanes were
             // chosen from the load; TYPLONK_MSM_LANES forces one class
             const uint32_t split = (lanes >= 2 && !ctx->msm_lanes) ? (uint32_t)(nb_used / 2) : (uint32_t)nb_used;
-            const bool chain = !standalone && ctx->msm_chain;
+            const bool chain = !standalone && (ctx->msm_chain < 0 ? m >= MSM_CHAIN_MIN_TERMS : ctx->msm_chain != 0);
             if (chain && ctx->accum_chain_live) HIPCHK(hipStreamWaitEvent(s, ctx->accum_chain, 0));
             StageTimer st(ctx, "msm_accum", s);
             launch_msm_accum(pts, offsets, sorted, (const uint32_t*)sb.order.p, (uint32_t)nb_used, cap, /*init=*/k > 0, lanes,
@@ -372,7 +372,9 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
 
 // ---- MsmQueue (host.hpp) --------------------------------------------------------------------------------------------
 MsmQueue::MsmQueue(typlonk_ctx* c, const SrsEntry* s, int first_lane)
-    : ctx(c), srs(s), lanes(std::max(1, std::min<int>(c->msm_inflight, typlonk_ctx::MSM_LANES))), lane_lo(0), next(0) {
+    : ctx(c), srs(s),
+      lanes(std::max(1, std::min<int>(c->msm_inflight ? c->msm_inflight : (s->len < MSM_FOUR_LANES_BELOW ? 4 : 3), typlonk_ctx::MSM_LANES))),
+      lane_lo(0), next(0) {
     set_first_lane(first_lane);
 }
 void MsmQueue::set_first_lane(int l) {
