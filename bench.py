@@ -219,7 +219,7 @@ def main() -> None:
                     help="N > 1: skip the extra measurement of prove() with every MSM sharded over the ranks")
     ap.add_argument("--tables", default="auto",
                     help="fixed-base tables built once per SRS (shard): window bits 14..20, 'none', or 'auto' = 20 on one "
-                         "GPU, the library's choice by shard length (17 below 2^19 points) on several")
+                         "GPU, the library's choice by shard length (15 below 2^16 points, 17 below 2^19) on several")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -686,7 +686,7 @@ def bench_cpu(args, ctx, sh, full, n, log_n, secret, out_xy, out_inf, result) ->
                 sid_l = sh.sid
                 if own_srs:
                     sid_l = ctx.srs_generate(secret, (1 << lg) + 3)
-                    ctx.srs_precompute(sid_l, 0)   # the library's choice by length (c = 17 below 2^19 points)
+                    ctx.srs_precompute(sid_l, 0)   # the library's choice by length (c = 15 below 2^16 points, 17 below 2^19)
                 ch = [fr_mont_limbs(0x1234567 + k) for k in range(4)]
                 run = lambda: ctx.prove(sid_l, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731,B023
                                         lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]))                   # noqa: B023

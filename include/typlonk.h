@@ -77,8 +77,8 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
 int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_t count, uint64_t* xy, uint8_t* inf);
 /* Optional fixed-base precomputation (the SRS is immutable per circuit, plonk/src/lib.rs:22): builds the
  * tables 2^(c*t) * g1[i] for every window t (T = ceil(256/c) copies of the SRS in HBM -- 15 for c = 17 and 17 for
- * c = 15, which slice centred scalars |k| < 2^254 --, c = window_bits in 14..20, or 0 = chosen by length: 17 below
- * 2^19 points -- an index shard --, else 20, whose top window still has 15 bits; with 0 an SRS shorter than
+ * c = 15, which slice centred scalars |k| < 2^254 --, c = window_bits in 14..20, or 0 = chosen by length: 15 below
+ * 2^16 points, 17 below 2^19 -- an index shard --, else 20, whose top window still has 15 bits; with 0 an SRS shorter than
  * TYPLONK_TABLES_AUTO_MIN_LEN points gets NO tables and the call returns TYPLONK_OK: 2^16 buckets for a handful of
  * terms would be slower than the plain path).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the

@@ -27,7 +27,7 @@ def main():
     sh = ShardedMsm(ctx, n + 3, rank, world, torch.device("cpu"))
     sh.generate_srs(secret)
     if os.environ.get("TABLES") == "auto" and (sh.hi - sh.lo) >= (1 << 14):
-        ctx.srs_precompute(sh.sid, 0)      # the library's choice by shard length (c = 17 below 2^19 points)
+        ctx.srs_precompute(sh.sid, 0)      # the library's choice by shard length (c = 15 below 2^16 points, 17 below 2^19)
     chain = SquaringChain(ctx, log_n)
     ch = [fr_mont_limbs(0xABC0 + k) for k in range(5)]
     args = (chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets, lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]))
