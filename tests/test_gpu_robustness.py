@@ -187,3 +187,50 @@ def test_auto_precompute_leaves_a_short_srs_alone(ctx):
         ctx.srs_precompute(big, 0)          # ... and a second build is refused
     ctx.srs_free(sid)
     ctx.srs_free(big)
+
+
+def test_automatic_window_and_lane_policy_keep_the_oracles_points(built, monkeypatch):
+    """typlonk_srs_precompute(0) picks the window by SRS length (15 below 2^16 points, 17 below 2^19, else 20: typlonk.h)
+    and a batch picks its lanes by size (free-running below 2^17 terms, four of them below 2^17 points; chained above:
+    host.hpp).  Either side of each switch the points are the CPU oracle's, and a batch equals its single calls, equals the
+    same batch under the other policy."""
+    import torch
+    import typlonk_amd
+    from oracle import coracle as CO
+
+    dev = torch.device("cuda", 0)
+    results = {}
+    for policy in ("default", "chained"):
+        rng = np.random.default_rng(0x515E)   # the same vectors under both policies
+        if policy == "chained":
+            monkeypatch.setenv("TYPLONK_MSM_CHAIN", "1")
+            monkeypatch.setenv("TYPLONK_MSM_INFLIGHT", "3")
+        c2 = typlonk_amd.Context(0)
+        try:
+            for length in ((1 << 14) + 1, (1 << 16) - 1, 1 << 16, (1 << 17) - 1, (1 << 17) + 3):
+                sid = c2.srs_generate(_limbs(5), length)
+                c2.srs_precompute(sid, 0)
+                vecs = []
+                for _ in range(5):
+                    x = rng.integers(0, 1 << 63, size=(length, 4), dtype=np.uint64)
+                    x[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+                    vecs.append(x)
+                dv = [torch.from_numpy(v.view(np.int64)).to(dev) for v in vecs]
+                torch.cuda.synchronize()
+                ms = [length, length - 1, length // 2, length - 3, length]
+                batch = c2.msm_batch_devptr(sid, [t.data_ptr() for t in dv], ms)
+                singles = [c2.msm_devptr(sid, t.data_ptr(), m) for t, m in zip(dv, ms)]
+                for b, s1 in zip(batch, singles):
+                    assert b[1] == s1[1] and (np.asarray(b[0]) == np.asarray(s1[0])).all()
+                results[(policy, length)] = [(np.asarray(b[0]).copy(), b[1]) for b in batch]
+                if policy == "default":
+                    xy, inf = c2.srs_download(sid)
+                    want = CO.msm_pippenger(vecs[0], xy, inf)[:2]
+                    assert batch[0][1] == want[1] and (np.asarray(batch[0][0]) == want[0]).all()
+                c2.srs_free(sid)
+        finally:
+            c2.close()
+    for (policy, length), pts in results.items():
+        if policy == "default":
+            for a, b in zip(pts, results[("chained", length)]):
+                assert a[1] == b[1] and (a[0] == b[0]).all()
