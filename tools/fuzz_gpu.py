@@ -120,6 +120,7 @@ while time.time() < t_end:
         whole = ctx.msm(full_sid, s, m)
         ctx.srs_free(full_sid)
         parts = []
+        shard_tables = int(rng.choice([-1, 0, 0, 15, 17]))
         sd = to_dev(s)
         for r in range(world):
             lo, hi = L * r // world, L * (r + 1) // world
@@ -127,6 +128,11 @@ while time.time() < t_end:
                 continue
             ps = ctx.srs_generate(secret, hi - lo, start=lo)
             ctx.srs_set_shard(ps, lo, L)
+            if shard_tables >= 0 and hi - lo >= 64:
+                try:
+                    ctx.srs_precompute(ps, shard_tables)   # 0 = the window the library picks for this shard's length
+                except typlonk_amd.TyplonkError:
+                    pass
             parts.append(ctx.msm_devptr(ps, sd.data_ptr(), m))
             ctx.srs_free(ps)
         acc = O.INF
@@ -135,7 +141,7 @@ while time.time() < t_end:
         stats["shard"] += 1
         if acc != O.g1_from_limbs([int(v) for v in whole[0]], whole[1]):
             stats["fail"] += 1
-            print(f"FAIL shard L={L} m={m} world={world} scalars={name} seed={SEED}", flush=True)
+            print(f"FAIL shard L={L} m={m} world={world} tables={shard_tables} scalars={name} seed={SEED}", flush=True)
     # ---- NTTs
     for _ in range(3):
         log_n = int(rng.integers(1, MAX_LOG + 2))
