@@ -82,7 +82,8 @@ int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_
  * TYPLONK_TABLES_AUTO_MIN_LEN points gets NO tables and the call returns TYPLONK_OK: 2^16 buckets for a handful of
  * terms would be slower than the plain path).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
- * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c doublings + T inversions per point.
+ * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c Jacobian doublings + ONE shared inversion per point
+ * (T * len * 48 bytes of scratch during the call; without it one inversion per table entry).
  * An MSM length the table-mode sort cannot handle (more than 2^22 terms with 20-bit windows) silently takes the
  * plain path over the same SRS: precomputation never turns a valid MSM into an error. */
 #define TYPLONK_TABLES_AUTO_MIN_LEN 16384
@@ -330,6 +331,12 @@ int typlonk_profile_get(typlonk_ctx* ctx, const char** names, float* ms, int cap
 /* Pippenger shape chosen for an m-term MSM: window bits c, number of windows, and the number of
  * group operations (mixed adds + full adds + doublings) the kernels execute for it. */
 int typlonk_msm_plan(typlonk_ctx* ctx, size_t m, uint32_t* window_bits, uint32_t* n_windows, uint64_t* group_ops);
+
+/* Self-test of the device's field inversion (the per-point `into_affine` of kzg/src/lib.rs:50 and kzg/src/srs.rs:20 is
+ * one Fq inversion): `count` pseudo-random and edge residues, lazily reduced up to 8p, inverted by the divsteps routine
+ * the kernels use and by the Fermat ladder a^(p-2); *mismatches = results that differ (or fail x * x^-1 = 1),
+ * *max_rounds = the largest number of 30-divstep rounds any call ran (proven bound: 37). */
+int typlonk_selftest_fq_inv(typlonk_ctx* ctx, uint64_t seed, size_t count, uint64_t* mismatches, uint32_t* max_rounds);
 
 const char* typlonk_version(void);
 

@@ -51,6 +51,51 @@ int shim_fq_inv_agree(const uint32_t* a, int la) {
         if (g.v[i] != f.v[i]) return 0;
     return 1;
 }
+// the divsteps inversion the device uses against the Fermat ladder AND the host's Euclid, digit for digit after
+// canonicalisation; la extra multiples of p on the input (values up to 8p).  Returns the number of 30-divstep rounds the
+// call ran (1..37), or -1 on a mismatch.
+int shim_fq_inv_divsteps_agree(const uint32_t* a, int la) {
+    const Fq30 x = lift(ldq(a), la);
+    int rounds = 0;
+    const Fq30 d = fq30_canon(fq30_inv_divsteps(x, &rounds));
+    const Fq30 f = fq30_canon(fq30_inv_fermat(fq30_canon(x))), g = fq30_canon(fq30_inv_gcd(x));
+    for (int i = 0; i < 13; ++i)
+        if (d.v[i] != f.v[i] || d.v[i] != g.v[i]) return -1;
+    return rounds;
+}
+// bulk form: n pseudo-random residues (xorshift seeded by `seed`, each lifted by (i mod 8) multiples of p when that keeps
+// it below 8p), divsteps against Euclid (the Fermat ladder is ~50 us a call: sampled every `fermat_every`-th).
+// Returns the number of mismatches; hist[r] counts the calls that ran r rounds (r <= 37).
+int shim_fq_inv_divsteps_bulk(uint64_t seed, int n, int fermat_every, uint32_t* hist) {
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    int bad = 0;
+    for (int it = 0; it < n; ++it) {
+        Fq30 x;
+        for (int i = 0; i < 13; ++i) x.v[i] = (uint32_t)next() & FQ30_MASK;
+        x.v[12] &= 0x000fffffu;                       // < 2^380 < p
+        if ((it & 15) == 3) for (int i = 1; i < 13; ++i) x.v[i] = 0;          // tiny values
+        if ((it & 15) == 7) { Fq30 pm; for (int i = 0; i < 13; ++i) pm.v[i] = fq30_kp(1, i); x = fq30_sub_lazy<1>(pm, x); x.v[12] &= 0x001fffffu; x = fq30_canon(x); }
+        const Fq30 xl = lift(x, it & 7 ? (it & 7) - 1 : 0);
+        int rounds = 0;
+        const Fq30 d = fq30_canon(fq30_inv_divsteps(xl, &rounds));
+        const Fq30 g = fq30_canon(fq30_inv_gcd(x));
+        bool ok = true;
+        for (int i = 0; i < 13; ++i) ok = ok && d.v[i] == g.v[i];
+        if (ok && fermat_every > 0 && it % fermat_every == 0) {
+            const Fq30 f = fq30_canon(fq30_inv_fermat(fq30_canon(x)));
+            for (int i = 0; i < 13; ++i) ok = ok && d.v[i] == f.v[i];
+        }
+        // and it IS the inverse: x * x^-1 = R (Montgomery one), unless x = 0
+        if (ok && !fq30_is_zero_exact(fq30_canon(x))) {
+            const Fq30 one = fq30_canon(fq30_mul(xl, d)), r1 = fq30_one();
+            for (int i = 0; i < 13; ++i) ok = ok && one.v[i] == r1.v[i];
+        }
+        if (!ok) ++bad;
+        if (rounds >= 0 && rounds <= 37) hist[rounds]++;
+    }
+    return bad;
+}
 int shim_fq_is_zero_mod(const uint32_t* a, int la) { return fq30_is_zero_mod(lift(ldq(a), la)) ? 1 : 0; }
 // pack(unpack(w)) on raw words (any 384-bit pattern whose value is < 2^384)
 void shim_fq_pack_unpack(const uint32_t* w, uint32_t* o) { uint32_t t[12]; memcpy(t, w, 48); uint32_t r[12]; fq30_pack(fq30_unpack(t), r); memcpy(o, r, 48); }

@@ -187,3 +187,100 @@ def test_config5_eight_ranks_prove_at_2_22_batched_and_six_openings():
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads(lines[0])
     assert out["sharded_prove_ok"] is True and out["world"] == 8 and out["log_n"] == 22
+
+
+def _native_ranks(world, log_n, tmp_path, tables=False, timeout=900):
+    """start `world` fresh rank processes of tests/dist_native_worker.py on GPU 0 over the stand-in exchange library"""
+    fake = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+    assert os.path.exists(fake), "tests/cpp/libfake_rccl.so not built (__graft_entry__.build())"
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, TYPLONK_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_S="300", TABLES="1" if tables else "0")
+        env.pop("TYPLONK_TEST_COMM_FAIL_STAGING", None)
+        if r == world - 1:
+            env["TYPLONK_TEST_COMM_FAIL_STAGING"] = "1"      # this rank's FIRST fold loses its staging copy
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_native_worker.py"), str(r), str(world),
+                                       str(tmp_path), str(log_n)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True, cwd=ROOT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    return [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,log_n,tables", [(2, 10, False), (8, 12, False), (2, 15, True)])
+def test_native_exchange_with_world_N_on_one_gpu(built, tmp_path, world, log_n, tables):
+    """The library's OWN exchange with more than one rank (round 4 had only ever run it with world = 1): `world` fresh,
+    torch-free processes share GPU 0, each with its own context, SRS shard and communicator; ncclAllGather is carried by
+    the test-only tests/cpp/libfake_rccl.so (RCCL refuses two ranks per device), selected through TYPLONK_RCCL_LIB -- the
+    record staging, the rank-order fold, the piecewise path (40 points > 32 per exchange), typlonk_prove's three
+    collectives per proof and both failure paths are the product's code, comm.hip.
+      * every rank returns the single-rank result, bit for bit: MSMs of n, n-1, 1, 0 terms, a batch of 40, a fold of
+        caller-held partial sums, the whole proof (commitments, evaluations, squeezed challenges);
+      * rank 1 passes m > len: IT gets TYPLONK_ERR_LENGTH, every other rank TYPLONK_ERR_COMM naming rank 1, and the next
+        call works (alone and inside a batch);
+      * the last rank's first staging copy fails (TYPLONK_TEST_COMM_FAIL_STAGING): it still joins the collective -- its
+        poisoned send buffer goes out -- so it gets TYPLONK_ERR_HIP, the others TYPLONK_ERR_COMM, nobody hangs."""
+    import numpy as np
+
+    import typlonk_amd
+    from dist_native_worker import SECRET, batch_lengths, pt, scalars
+    from typlonk_amd.capi import ERR_COMM, ERR_HIP, ERR_LENGTH
+    from typlonk_amd.circuits import SquaringChain, fr_mont_limbs
+
+    ranks = _native_ranks(world, log_n, tmp_path, tables)
+    n = 1 << log_n
+    ctx = typlonk_amd.Context(0)
+    try:
+        full = ctx.srs_generate(fr_mont_limbs(SECRET), n + 3)
+        buf = ctx.alloc(n)
+        buf.upload(scalars(n, 77))
+        want_msm = [pt(ctx.msm_devptr(full, buf.devptr(), m)) for m in (n, n - 1, 1, 0)]
+        ms = batch_lengths(n)
+        want_batch = [pt(p) for p in ctx.msm_batch_devptr(full, [buf.devptr()] * len(ms), ms)]
+        chain = SquaringChain(ctx, log_n)
+        pr = ctx.prove_native(full, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+        ident = pt((np.zeros(12, dtype=np.uint64), 1))
+        ident[0][6:] = [int(v) for v in ctx.msm_devptr(full, buf.devptr(), 0)[0][6:]]     # the (0, 1, inf) encoding
+        for r, o in enumerate(ranks):
+            assert o["msm"] == want_msm and o["batch"] == want_batch and o["fold"] == want_msm[0], r
+            assert o["fail_next"] == want_msm[0], r
+            assert o["proof"]["commit"] == [pt(p) for p in pr["commit"]] and o["proof"]["z"] == pt(pr["z_commit"]), r
+            assert o["proof"]["t"] == [pt(p) for p in pr["t_commit"]] and o["proof"]["w"] == [pt(p) for p in pr["witness"]], r
+            assert o["proof"]["evals"] == [[int(v) for v in e] for e in pr["evals"]], r
+            assert o["proof"]["ch"] == {k: [int(v) for v in val] for k, val in pr["challenges"].items()}, r
+            # failure of rank 1
+            for key in ("fail", "fail_batch"):
+                code, msg = o[key]
+                if r == 1:
+                    assert code == ERR_LENGTH, (r, key, o[key])
+                else:
+                    assert code == ERR_COMM and "rank 1" in msg, (r, key, o[key])
+            # staging failure of the last rank
+            code, msg = o["staging"]
+            if r == world - 1:
+                assert code == ERR_HIP and "staging" in msg, o["staging"]
+            else:
+                assert code == ERR_COMM and f"rank {world - 1}" in msg and "stage" in msg, o["staging"]
+            assert o["staging_next"][1] == 1, r          # the sum of `world` identities, through a working exchange
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_native_exchange_world_N_from_plain_cpp_processes(built, tmp_path, world):
+    """the same with no Python in the ranks: tests/cpp/test_comm_ranks_host forks `world` fresh copies of itself before
+    touching the GPU; each is a rank on GPU 0 that checks the sharded MSMs (single, batch of 40) against a plain SRS it
+    also holds, and the failure protocol (m > len on rank 1, a null output on rank 0)"""
+    fake = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_comm_ranks_host")
+    env = dict(os.environ, TYPLONK_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_S="300")
+    r = subprocess.run([exe, str(world), str(tmp_path)], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and f"all {world} ranks ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -357,6 +357,61 @@ def test_fixed_base_tables_give_identical_results(ctx, c):
         ctx.srs_free(sid)
 
 
+def test_device_inversion_divsteps_equals_fermat_ladder(ctx):
+    """the SIMT inversion the kernels use (Bernstein-Yang divsteps, fq30.hpp) against the Fermat ladder a^(p-2) on the
+    device: 2^20 random and edge residues (0, 1, 2, p-1, p-2, one-limb values), lazily reduced up to 8p, digit for digit,
+    and x * x^-1 = 1; no call runs more 30-divstep rounds than the proven bound"""
+    bad, rounds = ctx.selftest_fq_inv(1 << 20, seed=0x5EED)
+    assert bad == 0
+    assert 1 <= rounds <= 37
+    bad, rounds = ctx.selftest_fq_inv(1 << 16, seed=7)
+    assert bad == 0 and rounds <= 37
+
+
+@pytest.mark.parametrize("c", [15, 20])
+def test_fixed_base_tables_with_identity_bases(ctx, c):
+    """the table walk shares ONE inversion per base across its column of entries (srs_gen.hip): identity bases in the
+    SRS -- s = 0 gives (G, inf, inf, ...), and a loaded vector with identities in the middle -- must stay identities in
+    every table and must not disturb their neighbours"""
+    from oracle import coracle as CO
+
+    n = 1 << 14
+    rng = np.random.default_rng(100 + c)
+    sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+    # s = 0
+    z = ctx.srs_generate(np.zeros(4, dtype=np.uint64), n)
+    zt = ctx.srs_generate(np.zeros(4, dtype=np.uint64), n)
+    ctx.srs_precompute(zt, c)
+    a, ai = ctx.msm(z, sc)
+    b, bi = ctx.msm(zt, sc)
+    assert (a == b).all() and ai == bi
+    # identities sprinkled into a real SRS (every 7th base, the first and the last)
+    s_limbs = np.array(O.fr_to_mont_limbs(0xABCDEF0123456789), dtype=np.uint64)
+    g = ctx.srs_generate(s_limbs, n)
+    xy, inf = ctx.srs_download(g)
+    inf = np.ascontiguousarray(inf).copy()
+    xy = np.ascontiguousarray(xy).copy()
+    holes = np.zeros(n, dtype=bool)
+    holes[::7] = True
+    holes[-1] = True
+    inf[holes] = 1
+    xy[holes] = 0
+    xy[holes, 6:] = np.array(O.fq_to_mont_limbs(1), dtype=np.uint64)   # ark-ec identity: (0, 1, inf)
+    plain = ctx.srs_load(xy, inf)
+    tab = ctx.srs_load(xy, inf)
+    ctx.srs_precompute(tab, c)
+    a, ai = ctx.msm(plain, sc)
+    b, bi = ctx.msm(tab, sc)
+    assert (a == b).all() and ai == bi
+    r, ri = CO.msm_reference(sc[:1024], xy[:1024], inf[:1024])
+    small = ctx.srs_load(xy[:1024], inf[:1024])
+    got, gi = ctx.msm(small, sc[:1024])
+    assert (got == r).all() and gi == ri
+    for sid in (z, zt, g, plain, tab, small):
+        ctx.srs_free(sid)
+
+
 def test_fixed_base_tables_commit_identity_2_18(ctx):
     """table mode (c = 20, the shape bench.py uses) at 2^18 terms: commit(p) == [p(s)]G, plus the batch
     entry point and the n-1 / n-3 lengths of prove()"""

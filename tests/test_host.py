@@ -87,6 +87,26 @@ def test_fq30_arithmetic_vs_bigint(shim):
         assert (o == w).all()
 
 
+def test_fq30_divsteps_inversion_equals_fermat_and_euclid(shim):
+    """the device's SIMT inversion (Bernstein-Yang divsteps on 13 signed 30-bit limbs, fq30.hpp) digit for digit against
+    the Fermat ladder a^(p-2) and the host's binary Euclid: edge values, inputs lifted up to 8p, 200,000 random residues
+    (every 500th also through the ladder), x * x^-1 = 1, and the round count stays inside the proven bound of 37"""
+    rnd = random.Random(11)
+    edges = [0, 1, 2, 3, O.P - 1, O.P - 2, (O.P + 1) // 2, (O.P - 1) // 2, 1 << 30, (1 << 30) - 1, 1 << 380, (1 << 380) - 1,
+             (1 << 381) % O.P, pow(2, -1, O.P), pow(3, -1, O.P), O.P - (1 << 30)]
+    for a in edges + [rnd.randrange(O.P) for _ in range(60)]:
+        for la in (0, 1, 3, 7):                     # a + la * p < 8p
+            r = shim.shim_fq_inv_divsteps_agree(u32p(_fq(a)), la)
+            assert 0 <= r <= 37, (a, la, r)
+    hist = np.zeros(38, dtype=np.uint32)
+    shim.shim_fq_inv_divsteps_bulk.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    assert shim.shim_fq_inv_divsteps_bulk(0x5EED, 200_000, 500, hist.ctypes.data) == 0
+    assert int(hist.sum()) == 200_000 and int(hist[37:].sum()) < 200_000
+    used = np.nonzero(hist)[0]
+    assert used.max() <= 37
+    print("divstep rounds histogram:", {int(k): int(hist[k]) for k in used})
+
+
 def _pt(p):
     if p is None:
         return np.zeros(12, dtype=np.uint64)

@@ -111,7 +111,7 @@ def build_host_tests(force: bool = False) -> list[str]:
            os.path.join(CSRC, "ff.hpp"), os.path.join(CSRC, "fq30.hpp"), os.path.join(CSRC, "g1_host64.hpp"),
            os.path.join(CSRC, "transcript.hpp"), LIB]
     for name in ("test_poly_host", "test_kzg_host", "test_plonk_host", "test_pairing_host", "test_circuit_tables_host", "test_circuit_host",
-                 "test_comm_host"):
+                 "test_comm_host", "test_comm_ranks_host"):
         src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
         out = os.path.join(ROOT, "tests", "cpp", name)
         if force or _stale(out, [src] + hdr):
@@ -121,10 +121,21 @@ def build_host_tests(force: bool = False) -> list[str]:
     return outs
 
 
+def build_fake_rccl(force: bool = False) -> str:
+    """tests/cpp/libfake_rccl.so: the test-only stand-in for librccl (N ranks on one GPU over POSIX shared memory) that
+    tests/test_gpu_dist.py selects through TYPLONK_RCCL_LIB -- never loaded by the product on its own"""
+    src = os.path.join(ROOT, "tests", "cpp", "fake_rccl.cpp")
+    out = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+    if force or _stale(out, [src]):
+        _run([hipcc_path(), "-O2", "-std=c++17", "-shared", "-fPIC", "-x", "hip", "--offload-arch=gfx950", src, "-o", out, "-lrt"])
+    return out
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_host_shim(force)
     build_host_tests(force)
+    build_fake_rccl(force)
 
 
 if __name__ == "__main__":

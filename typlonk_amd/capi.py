@@ -26,7 +26,7 @@ SYMBOLS = [
     "typlonk_prover_round3", "typlonk_prover_round3_evals", "typlonk_prover_round4_batched", "typlonk_prover_free",
     "typlonk_prove", "typlonk_transcript_challenges", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
-    "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan",
+    "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan", "typlonk_selftest_fq_inv",
     "typlonk_version",
     "typlonk_comm_available", "typlonk_comm_unique_id", "typlonk_comm_init", "typlonk_comm_destroy", "typlonk_comm_info", "typlonk_comm_fold_g1",
     "typlonk_msm_g1_sharded_devptr", "typlonk_msm_g1_sharded_batch_devptr", "typlonk_g1_fold_records_host",
@@ -156,6 +156,7 @@ def load_library() -> C.CDLL:
     lib.typlonk_profile_get.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     lib.typlonk_msm_plan.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint64)]
+    lib.typlonk_selftest_fq_inv.argtypes = [vp, C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     lib.typlonk_version.restype = C.c_char_p
     _lib = lib
     return lib
@@ -426,6 +427,12 @@ class Context:
         c, w, ops = C.c_uint32(), C.c_uint32(), C.c_uint64()
         self._chk(self.lib.typlonk_msm_plan(self.h, m, C.byref(c), C.byref(w), C.byref(ops)))
         return c.value, w.value, ops.value
+
+    def selftest_fq_inv(self, count: int, seed: int = 1):
+        """device divsteps inversion vs the Fermat ladder on `count` residues -> (mismatches, max 30-divstep rounds)"""
+        bad, rounds = C.c_uint64(), C.c_uint32()
+        self._chk(self.lib.typlonk_selftest_fq_inv(self.h, seed, count, C.byref(bad), C.byref(rounds)))
+        return bad.value, rounds.value
 
     # ---- NTT ------------------------------------------------------------------------------
     @staticmethod

@@ -65,6 +65,15 @@ namespace tyh {
             return fail(ctx, TYPLONK_ERR_COMM, std::string(#expr) + ": " + rccl_api()->GetErrorString(_r));           \
     } while (0)
 
+// TYPLONK_TEST_COMM_FAIL_STAGING=<k>: the k-th fold of this process (1-based) behaves as if its staging copy had failed
+// -- the one local failure between "decided to fold" and the collective that cannot be provoked from outside
+// (tests/test_gpu_dist.py: the peers must get TYPLONK_ERR_COMM, not a hang, and the next fold must work).
+static bool comm_test_fail_staging() {
+    static const int target = [] { const char* e = getenv("TYPLONK_TEST_COMM_FAIL_STAGING"); return e ? atoi(e) : 0; }();
+    static int calls = 0;
+    return target > 0 && ++calls == target;
+}
+
 void comm_release(typlonk_ctx* ctx) {
     Comm& c = ctx->comm;
     if (c.comm) (void)rccl_api()->CommDestroy((ncclComm_t)c.comm);
@@ -74,15 +83,20 @@ void comm_release(typlonk_ctx* ctx) {
     c = Comm{};
 }
 
-// The exchange buffers are allocated ONCE, by typlonk_comm_init (COMM_CAP records: more than the 9 points of a prover
-// round): a fold never allocates, so no rank can fail locally between "decided to fold" and the collective and leave
-// its peers waiting.  Longer point lists go through in pieces of COMM_CAP records (comm_fold).
+// The exchange buffers are allocated ONCE, by typlonk_comm_init BEFORE it joins ncclCommInitRank (COMM_CAP records: more
+// than the 9 points of a prover round): a rank that cannot allocate never becomes a member, and a fold never allocates,
+// so no member can fail locally between "decided to fold" and the collective and leave its peers waiting.  Longer point
+// lists go through in pieces of COMM_CAP records (comm_fold).
+// The send buffer is kept POISONED -- every flag word all ones, which the fold reads as "this rank failed" -- except
+// between a successful staging copy and the all-gather that follows it: if the copy fails, the rank still joins the
+// collective and what its peers receive says so.
 constexpr size_t COMM_CAP = 32;
-int comm_reserve(typlonk_ctx* ctx) {
+int comm_reserve(typlonk_ctx* ctx, int world) {
     Comm& c = ctx->comm;
     HIPCHK(hipMalloc((void**)&c.d_send, COMM_CAP * COMM_REC * 8));
-    HIPCHK(hipMalloc((void**)&c.d_recv, (size_t)c.world * COMM_CAP * COMM_REC * 8));
-    HIPCHK(hipHostMalloc((void**)&c.h_buf, (size_t)(c.world + 1) * COMM_CAP * COMM_REC * 8));
+    HIPCHK(hipMalloc((void**)&c.d_recv, (size_t)world * COMM_CAP * COMM_REC * 8));
+    HIPCHK(hipHostMalloc((void**)&c.h_buf, (size_t)(world + 1) * COMM_CAP * COMM_REC * 8));
+    HIPCHK(hipMemset(c.d_send, 0xff, COMM_CAP * COMM_REC * 8));
     c.cap = COMM_CAP;
     return TYPLONK_OK;
 }
@@ -119,8 +133,18 @@ int comm_fold(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count, int lo
         }
     }
     hipStream_t s = ctx->stream;
-    HIPCHK(hipMemcpyAsync(c.d_send, out, count * COMM_REC * 8, hipMemcpyHostToDevice, s));
-    NCCLCHK(rccl_api()->AllGather(c.d_send, c.d_recv, count * COMM_REC, ncclUint64, (ncclComm_t)c.comm, s));
+    // From here to the all-gather there is no early return: whatever goes wrong locally, the rank joins the collective.
+    // A staging copy that fails leaves the poisoned send buffer in place (comm_reserve), i.e. flagged records.
+    hipError_t stage = comm_test_fail_staging() ? hipErrorUnknown : hipMemcpyAsync(c.d_send, out, count * COMM_REC * 8, hipMemcpyHostToDevice, s);
+    const ncclResult_t gathered = rccl_api()->AllGather(c.d_send, c.d_recv, count * COMM_REC, ncclUint64, (ncclComm_t)c.comm, s);
+    (void)hipMemsetAsync(c.d_send, 0xff, c.cap * COMM_REC * 8, s);   // poisoned again for the next fold
+    if (stage != hipSuccess) {
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+        return fail(ctx, TYPLONK_ERR_HIP, std::string("staging the records for the exchange: ") + hipGetErrorString(stage) +
+                                              " (the peers were told: this rank's records went out flagged)");
+    }
+    if (gathered != ncclSuccess) return fail(ctx, TYPLONK_ERR_COMM, std::string("ncclAllGather: ") + rccl_api()->GetErrorString(gathered));
     HIPCHK(hipMemcpyAsync(back, c.d_recv, (size_t)c.world * count * COMM_REC * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (local_rc) return fail(ctx, local_rc, local_err);   // (its flagged records made every peer fail too)
@@ -128,6 +152,8 @@ int comm_fold(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count, int lo
     rc = typlonk_g1_fold_records_host(back, (size_t)c.world, count, xy, inf, &failed);
     if (rc == TYPLONK_ERR_COMM) {
         const uint64_t flag = back[(size_t)failed * count * COMM_REC + 12];
+        if ((flag >> 32) == 0xffffffffull)
+            return fail(ctx, rc, "rank " + std::to_string(failed) + " could not stage its records for the exchange (a HIP error on that rank)");
         return fail(ctx, rc, "rank " + std::to_string(failed) + " failed before the exchange (its error code " +
                                  std::to_string(-(int)(flag >> 32)) + ")");
     }
@@ -164,19 +190,25 @@ int typlonk_comm_init(typlonk_ctx* ctx, const uint8_t id[TYPLONK_COMM_ID_BYTES],
     RcclApi* api = rccl_api();
     if (!api->err.empty()) return fail(ctx, TYPLONK_ERR_COMM, api->err);
     HIPCHK(hipSetDevice(ctx->device));
-    ncclUniqueId u;
-    memcpy(&u, id, sizeof(u));
-    ncclComm_t comm = nullptr;
-    NCCLCHK(api->CommInitRank(&comm, world, u, rank));
-    ctx->comm.comm = comm;
-    ctx->comm.rank = rank;
-    ctx->comm.world = world;
-    const int rc = comm_reserve(ctx);   // every rank allocates here, before any fold: a failure is reported by this call
+    // Buffers first: a rank that cannot allocate fails HERE, before it is a member -- as a rank that never called. Once
+    // ncclCommInitRank has returned on every rank there is nothing left that can fail on one of them alone.
+    const int rc = comm_reserve(ctx, world);
     if (rc) {
         const std::string msg = ctx->err;
         comm_release(ctx);
         return fail(ctx, rc, msg);
     }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = api->CommInitRank(&comm, world, u, rank);
+    if (r != ncclSuccess) {
+        comm_release(ctx);
+        return fail(ctx, TYPLONK_ERR_COMM, std::string("ncclCommInitRank: ") + api->GetErrorString(r));
+    }
+    ctx->comm.comm = comm;
+    ctx->comm.rank = rank;
+    ctx->comm.world = world;
     return TYPLONK_OK;
 }
 
@@ -200,28 +232,50 @@ int typlonk_comm_info(const typlonk_ctx* ctx, int* rank, int* world) {
 }
 
 int typlonk_comm_fold_g1(typlonk_ctx* ctx, uint64_t* xy, uint8_t* inf, size_t count) {
-    if (!ctx || ((!xy || !inf) && count)) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    return comm_fold(ctx, xy, inf, count);
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    if (!ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
+    // a member's bad argument / device error is a local failure that still joins the collective (flagged records)
+    int rc = TYPLONK_OK;
+    const hipError_t he = hipSetDevice(ctx->device);
+    if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
+    if (xy && inf) return comm_fold(ctx, xy, inf, count, rc);
+    if (!count) return rc;
+    if (!rc) rc = fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    std::vector<uint64_t> spare_xy(12 * count, 0);
+    std::vector<uint8_t> spare_inf(count, 1);
+    return comm_fold(ctx, spare_xy.data(), spare_inf.data(), count, rc);
 }
 
 int typlonk_msm_g1_sharded_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* d_scalars, size_t m, uint64_t out_xy[12],
                                   uint8_t* out_inf) {
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     if (!ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
-    HIPCHK(hipSetDevice(ctx->device));
-    if (!out_xy || !out_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
-    const int rc = msm_run(ctx, srs_id, (const Fr*)d_scalars, m, out_xy, out_inf);
-    return comm_fold(ctx, out_xy, out_inf, 1, rc);   // a failed rank still joins the collective, flagged
+    // A member of the communicator: from here every path ends in the collective.  A bad argument or a device error is a
+    // LOCAL failure like any other -- it travels with flagged records instead of leaving the peers inside ncclAllGather.
+    int rc = TYPLONK_OK;
+    const hipError_t he = hipSetDevice(ctx->device);
+    if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
+    uint64_t spare_xy[12] = {0};
+    uint8_t spare_inf = 1;
+    if (!rc && (!out_xy || !out_inf)) rc = fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
+    if (!rc) rc = msm_run(ctx, srs_id, (const Fr*)d_scalars, m, out_xy, out_inf);
+    const bool have_out = out_xy && out_inf;
+    return comm_fold(ctx, have_out ? out_xy : spare_xy, have_out ? out_inf : &spare_inf, 1, rc);
 }
 
 int typlonk_msm_g1_sharded_batch_devptr(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m,
                                         size_t count, uint64_t* out_xy, uint8_t* out_inf) {
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     if (!ctx->comm.comm) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "no communicator on this context (typlonk_comm_init)");
-    HIPCHK(hipSetDevice(ctx->device));
-    if (!out_xy || !out_inf || !m) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
-    const int rc = msm_batch(ctx, srs_id, d_scalars, m, count, out_xy, out_inf);
-    return comm_fold(ctx, out_xy, out_inf, count, rc);   // one collective for the whole group; failures travel with it
+    // as above: every path of a member ends in the collective (`count` is what the ranks agree on)
+    int rc = TYPLONK_OK;
+    const hipError_t he = hipSetDevice(ctx->device);
+    if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
+    if (!rc && (!out_xy || !out_inf || !m || !d_scalars)) rc = fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (!rc) rc = msm_batch(ctx, srs_id, d_scalars, m, count, out_xy, out_inf);
+    if (out_xy && out_inf) return comm_fold(ctx, out_xy, out_inf, count, rc);   // one collective for the whole group
+    std::vector<uint64_t> spare_xy(12 * std::max<size_t>(count, 1), 0);
+    std::vector<uint8_t> spare_inf(std::max<size_t>(count, 1), 1);
+    return comm_fold(ctx, spare_xy.data(), spare_inf.data(), count, rc);
 }
 

@@ -121,7 +121,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
         (void)hipFree(kv.second.sig_ev);
     }
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
-    for (DevBuf* b : {&ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->quot_tab, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
+    for (DevBuf* b : {&ctx->srs_comb, &ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->quot_tab, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (SortBufs& sb : ws.sb)
             for (DevBuf* b : sb.all()) release(*b);

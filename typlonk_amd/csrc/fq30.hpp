@@ -67,6 +67,13 @@ TY_HD constexpr uint32_t fq30_cout_limb(int i) {
     return t[i];
 }
 
+// R^3 mod p: one Montgomery product with it turns (a R)^-1 into a^-1 R
+TY_HD constexpr uint32_t fq30_r3_limb(int i) {
+    constexpr uint32_t t[13] = {0x1347c98du, 0x2c2194ccu, 0x1b027ceau, 0x2b8cb5a5u, 0x1214bbdeu, 0x0b5efd04u, 0x39edd0bfu,
+                                0x1b2b39a4u, 0x32b00b66u, 0x1d1b6db4u, 0x3b8f0b8fu, 0x12c853b7u, 0x0006d0afu};
+    return t[i];
+}
+
 TY_HD Fq30 fq30_zero() {
     Fq30 r;
 #pragma unroll
@@ -537,22 +544,193 @@ inline Fq30 fq30_inv_gcd(const Fq30& a) {
         r.v[i] = (uint32_t)x & FQ30_MASK;
     }
     // (a R)^-1 -> a^-1 R: times R^2, i.e. one Montgomery product with R^3 mod p
-    constexpr uint32_t R3[13] = {0x1347c98du, 0x2c2194ccu, 0x1b027ceau, 0x2b8cb5a5u, 0x1214bbdeu, 0x0b5efd04u, 0x39edd0bfu,
-                                 0x1b2b39a4u, 0x32b00b66u, 0x1d1b6db4u, 0x3b8f0b8fu, 0x12c853b7u, 0x0006d0afu};
     Fq30 k;
-    for (int i = 0; i < 13; ++i) k.v[i] = R3[i];
+    for (int i = 0; i < 13; ++i) k.v[i] = fq30_r3_limb(i);   // (a R)^-1 -> a^-1 R
     return fq30_mul(r, k);
 }
 
-// Fermat ladder a^(p-2): the device form (srs_gen.hip), and the reference the host's Euclid inversion is tested against
+// ---- SIMT inversion: Bernstein-Yang divsteps ("safegcd") on the 13 x 30-bit limbs ----------------------------------
+// The device had only the Fermat ladder below (a^(p-2): 380 squarings + ~190 multiplications = 551 multiplication times
+// per wavefront, profiles/r04_ubench4_pricing.txt).  This is the branch-free divstep recurrence
+//     divstep(delta, f, g) = (1 - delta, g, (g - f)/2)               if delta > 0 and g odd
+//                            (1 + delta, f, (g + (g mod 2) f)/2)     otherwise
+// started at (1, p, a): Theorem 11.2 of Bernstein-Yang ("Fast constant-time gcd computation and modular inversion",
+// TCHES 2019) bounds the number of divsteps that reach g = 0 by floor((49 d + 57)/17) = 1101 for d = 381 bits, i.e.
+// FQ30_DIVSTEP_ROUNDS = 37 rounds of 30.  A round runs 30 divsteps on the low 30 bits of f and g with 32-bit full-rate
+// instructions only, collecting the transition matrix t = (u v; q r), 2^30 (f', g') = t (f, g), |u| + |v| <= 2^30,
+// |q| + |r| <= 2^30; then applies t to the full-width (f, g) (exact division by 2^30) and to the Bezout pair (d, e),
+// which is kept mod p in (-2p, p) with the multiple of p added that makes the division by 2^30 exact.  Invariant:
+// d * a = f and e * a = g (mod p).  At g = 0: f = +-gcd = +-1 and a^-1 = +-d; a = 0 leaves d = 0 (0 -> 0).
+// Integers are 13 signed limbs: limbs 0..11 in [0, 2^30), limb 12 carries the sign.
+// A lane never leaves the loop alone: the exit test is wave-uniform (all lanes at g = 0; once there, further rounds
+// change neither f nor d), so the usual count is the slowest lane's ~25 rounds, the bound 37 (-DFQ30_INV_FIXED_ROUNDS:
+// always 37, for a data-independent instruction stream).
+constexpr int FQ30_DIVSTEP_ROUNDS = 37;
+constexpr uint32_t FQ30_PINV = 0x00030003u;   // p^-1 mod 2^30
+
+// 30 divsteps on the low words; eta = -delta.  Only bit 0 of g is ever inspected and step i sees input bits <= i, so the
+// two spare bits of the 32-bit registers may hold anything.  t = {u, v, q, r}.
+TY_HD int32_t fq30_divsteps30(int32_t eta, uint32_t f, uint32_t g, int32_t (&t)[4]) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+#pragma unroll
+    for (int i = 0; i < 30; ++i) {
+        uint32_t c1 = (uint32_t)(eta >> 31);              // delta > 0
+        const uint32_t c2 = 0u - (g & 1u);                // g odd
+        // g <- g +- f (minus when delta > 0), likewise the second matrix row
+        g += ((f ^ c1) - c1) & c2;
+        q += ((u ^ c1) - c1) & c2;
+        r += ((v ^ c1) - c1) & c2;
+        c1 &= c2;                                         // swap: delta > 0 and g odd
+        eta = (int32_t)(((uint32_t)eta ^ c1) + ~c1);      // swap: -eta - 1 = ~eta; else eta - 1
+        f += g & c1;                                      // swap: f <- old g
+        u += q & c1;
+        v += r & c1;
+        g >>= 1;
+        u += u;                                           // the f-row is scaled instead of halving the g-row
+        v += v;
+    }
+    t[0] = (int32_t)u;
+    t[1] = (int32_t)v;
+    t[2] = (int32_t)q;
+    t[3] = (int32_t)r;
+    return eta;
+}
+// acc += a * b on signed 32-bit factors: ONE v_mad_i64_i32 on the device.  The limbs below the top one are known to be
+// non-negative (they were just masked), the compiler therefore zero-extends them, and a product of a sign-extended and a
+// zero-extended factor has no single instruction: it emitted three multiplier instructions and two moves per product.
+// Passing the limb through an empty asm hides the known bits and costs nothing (1155 -> 960 instructions per round).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQ30_OPAQUE(x) asm("" : "+v"(x))
+#else
+#define FQ30_OPAQUE(x) ((void)0)
+#endif
+#define FQ30_SMAD_VV(acc, a, b) do { int32_t _b = (b); FQ30_OPAQUE(_b); (acc) += (int64_t)(a) * (int64_t)_b; } while (0)
+#define FQ30_SMAD_VS(acc, a, b) ((acc) += (int64_t)(a) * (int64_t)(b))
+// the first product of a column takes the shifted carry as its addend; pinned, or the compiler starts the column from zero
+// and merges the carry with a separate 64-bit addition (48 per round)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQ30_SMAD_FIRST(acc, a, b) do { uint64_t _co; asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(_co) : "v"(a), "v"(b)); } while (0)
+#else
+#define FQ30_SMAD_FIRST(acc, a, b) FQ30_SMAD_VV(acc, a, b)
+#endif
+
+// (f, g) <- t (f, g) / 2^30, exact
+TY_HD void fq30_divsteps_update_fg(int32_t (&f)[13], int32_t (&g)[13], const int32_t (&t)[4]) {
+    int64_t cf = 0, cg = 0;
+    FQ30_SMAD_VV(cf, t[0], f[0]);
+    FQ30_SMAD_VV(cf, t[1], g[0]);
+    FQ30_SMAD_VV(cg, t[2], f[0]);
+    FQ30_SMAD_VV(cg, t[3], g[0]);
+    cf >>= 30;
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 13; ++i) {
+        FQ30_SMAD_FIRST(cf, t[0], f[i]);
+        FQ30_SMAD_FIRST(cg, t[2], f[i]);
+        FQ30_SMAD_VV(cf, t[1], g[i]);
+        FQ30_SMAD_VV(cg, t[3], g[i]);
+        f[i - 1] = (int32_t)((uint32_t)cf & FQ30_MASK);
+        g[i - 1] = (int32_t)((uint32_t)cg & FQ30_MASK);
+        cf >>= 30;
+        cg >>= 30;
+    }
+    f[12] = (int32_t)cf;
+    g[12] = (int32_t)cg;
+}
+// (d, e) <- t (d, e) / 2^30 mod p, both kept in (-2p, p): with d + [d<0] p and e + [e<0] p in (-p, p) and
+// |u| + |v| <= 2^30 the combination is in (-2^30 p, 2^30 p); subtracting k p, 0 <= k < 2^30 chosen so that the low 30
+// bits vanish, leaves (-2^31 p, 2^30 p) before the exact shift.
+TY_HD void fq30_divsteps_update_de(int32_t (&d)[13], int32_t (&e)[13], const int32_t (&t)[4]) {
+    const int32_t sd = d[12] >> 31, se = e[12] >> 31;
+    int32_t md = (t[0] & sd) + (t[1] & se), me = (t[2] & sd) + (t[3] & se);
+    int64_t cd = 0, ce = 0;
+    FQ30_SMAD_VV(cd, t[0], d[0]);
+    FQ30_SMAD_VV(cd, t[1], e[0]);
+    FQ30_SMAD_VV(ce, t[2], d[0]);
+    FQ30_SMAD_VV(ce, t[3], e[0]);
+    md -= (int32_t)((FQ30_PINV * (uint32_t)cd + (uint32_t)md) & FQ30_MASK);
+    me -= (int32_t)((FQ30_PINV * (uint32_t)ce + (uint32_t)me) & FQ30_MASK);
+    FQ30_SMAD_VS(cd, md, (int32_t)fq30_kp(1, 0));
+    FQ30_SMAD_VS(ce, me, (int32_t)fq30_kp(1, 0));
+    cd >>= 30;
+    ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 13; ++i) {
+        FQ30_SMAD_FIRST(cd, t[0], d[i]);
+        FQ30_SMAD_FIRST(ce, t[2], d[i]);
+        FQ30_SMAD_VV(cd, t[1], e[i]);
+        FQ30_SMAD_VV(ce, t[3], e[i]);
+        FQ30_SMAD_VS(cd, md, (int32_t)fq30_kp(1, i));
+        FQ30_SMAD_VS(ce, me, (int32_t)fq30_kp(1, i));
+        d[i - 1] = (int32_t)((uint32_t)cd & FQ30_MASK);
+        e[i - 1] = (int32_t)((uint32_t)ce & FQ30_MASK);
+        cd >>= 30;
+        ce >>= 30;
+    }
+    d[12] = (int32_t)cd;
+    e[12] = (int32_t)ce;
+}
+
+// a^-1 by divsteps; input normalised and < 8p, output < 1.01 p (as fq30_inv_fermat).  0 -> 0.
+// `rounds_out` (host tests): the number of rounds this call ran.
+TY_HD Fq30 fq30_inv_divsteps(const Fq30& a, int* rounds_out = nullptr) {
+    const Fq30 c = fq30_canon(a);
+    int32_t f[13], g[13], d[13], e[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        f[i] = (int32_t)fq30_kp(1, i);
+        g[i] = (int32_t)c.v[i];
+        d[i] = 0;
+        e[i] = 0;
+    }
+    e[0] = 1;
+    int32_t eta = -1;
+    int rounds = 0;
+#pragma unroll 1
+    for (; rounds < FQ30_DIVSTEP_ROUNDS; ++rounds) {
+#if !defined(FQ30_INV_FIXED_ROUNDS)
+        uint32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) nz |= (uint32_t)g[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!__any(nz != 0)) break;
+#else
+        if (nz == 0) break;
+#endif
+#endif
+        int32_t t[4];
+        eta = fq30_divsteps30(eta, (uint32_t)f[0], (uint32_t)g[0], t);
+        fq30_divsteps_update_de(d, e, t);
+        fq30_divsteps_update_fg(f, g, t);
+    }
+    if (rounds_out) *rounds_out = rounds;
+    // +-d + 2p is in (0, 4p): sign of f decides, no conditional correction needed before the Montgomery product
+    const int32_t sf = f[12] >> 31;
+    Fq30 x;
+    int32_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int32_t s = ((d[i] ^ sf) - sf) + (int32_t)fq30_kp(2, i) + cy;
+        x.v[i] = (uint32_t)s & FQ30_MASK;
+        cy = s >> 30;
+    }
+    Fq30 k;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) k.v[i] = fq30_r3_limb(i);
+    return fq30_mul(x, k);
+}
+
+// Fermat ladder a^(p-2): the round-1..4 device form, kept as the reference the two other inversions are tested against
 TY_HD Fq30 fq30_inv_fermat(const Fq30& a);
 
-// a^-1; input < 8p, output < 1.01 p.  0 -> 0.
+// a^-1; input < 8p, output < 1.01 p.  0 -> 0.  Host: binary Euclid on 64-bit words; device: divsteps.
 TY_HD Fq30 fq30_inv(const Fq30& a) {
 #if !defined(__HIP_DEVICE_COMPILE__)
     return fq30_inv_gcd(a);
-#else
+#elif defined(FQ30_INV_FERMAT)
     return fq30_inv_fermat(a);
+#else
+    return fq30_inv_divsteps(a);
 #endif
 }
 

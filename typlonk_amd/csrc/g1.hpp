@@ -175,6 +175,55 @@ TY_HD G1Affine g1_to_affine(const G1Xyzz& p) {
     return r;
 }
 
+// ---- Jacobian doubling chains (fixed-base table set-up, srs_gen.hip) ---------------------------------------------------
+// (X, Y, Z): x = X/Z^2, y = Y/Z^3.  A run of doublings costs 3S + 2M + one two-product reduction each (~6.0
+// multiplication times) against the 8.0 of g1_dbl, and carries ONE denominator, so that a whole column of table entries
+// can be normalised with one shared inversion.  Invariants as for XYZZ: X < 5.1, Y < 3.2, Z < 1.1 (units of p).
+// Z = 0 (mod p) is the identity.
+struct G1Jac {
+    Fq30 x, y, z;
+    TY_HD bool is_inf() const { return fq30_is_zero_mod(z); }
+    static TY_HD G1Jac from_affine(const G1Affine& p) {   // p must not be the identity
+        G1Jac r;
+        r.x = p.x;
+        r.y = p.y;
+        r.z = fq30_one();
+        return r;
+    }
+};
+// 2*P.  With B = Y^2, V = 4B, S = X V = 4XY^2, M = 3X^2:  X3 = M^2 - 2S,  Y3 = M (S - X3) - 8B^2,  Z3 = 2YZ.
+// (The identity doubles to itself: Z3 = 0; the other coordinates are then meaningless but bounded.)
+TY_HD G1Jac g1_jac_dbl(const G1Jac& p) {
+    G1Jac r;
+    const Fq30 b = fq30_sqr(p.y);                                      // m(3.2,3.2) < 1.02
+    const Fq30 v = fq30_mulk_lazy<2>(fq30_mulk_lazy<2>(b));            // < 4.1
+    const Fq30 s = fq30_mul(p.x, v);                                   // m(5.1,4.1) < 1.04
+    const Fq30 m = fq30_mulk_lazy<3>(fq30_sqr(p.x));                   // 3 * m(5.1,5.1) < 3.2
+    r.x = fq30_sub_lazy<3>(fq30_sqr(m), fq30_mulk_lazy<2>(s));         // m(3.2,3.2) + 3 < 4.1   (2s < 2.1 <= 3)
+    const Fq30 t = fq30_sub_lazy<5>(s, r.x);                           // 1.04 + 5 < 6.1         (X3 < 4.1 <= 5)
+    r.y = g1_y3(m, t, fq30_mulk_lazy<2>(b), v);                        // m t - 2b v = m t - 8 b^2:  1 + (3.2*6.1 + 4*4.1)/630 < 1.06   (2b < 2.1 <= 4)
+    r.z = fq30_mul(fq30_mulk_lazy<2>(p.y), p.z);                       // m(6.4,1.1) < 1.02
+    return r;
+}
+// the same point in XYZZ form (ZZ = Z^2, ZZZ = Z^3)
+TY_HD G1Xyzz g1_jac_to_xyzz(const G1Jac& p) {
+    if (p.is_inf()) return G1Xyzz::inf();
+    G1Xyzz r;
+    r.x = p.x;
+    r.y = p.y;
+    r.zz = fq30_sqr(p.z);                                              // < 1.01
+    r.zzz = fq30_mul(r.zz, p.z);                                       // < 1.01
+    return r;
+}
+// canonical affine form given zinv = 1/Z
+TY_HD G1Affine g1_jac_to_affine_with(const G1Jac& p, const Fq30& zinv) {
+    const Fq30 zi2 = fq30_sqr(zinv);                                   // < 1.01
+    G1Affine r;
+    r.x = fq30_canon(fq30_mul(p.x, zi2));
+    r.y = fq30_canon(fq30_mul(p.y, fq30_mul(zi2, zinv)));
+    return r;
+}
+
 // k * P for a small unsigned k, double-and-add.
 TY_HD G1Xyzz g1_mul_small(const G1Xyzz& p, uint32_t k) {
     G1Xyzz acc = G1Xyzz::inf();

@@ -133,6 +133,7 @@ struct typlonk_ctx {
     uint32_t next_srs = 1;
     std::map<uint32_t, tyh::CircuitEntry> circuits;
     uint32_t next_circuit = 1;
+    tyh::DevBuf srs_comb;          // fixed-base comb of G (typlonk_srs_generate, srs_gen.hip)
     // MSM
     tyh::DevBuf scal;
     static constexpr int MSM_LANES = 4;

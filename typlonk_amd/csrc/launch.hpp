@@ -100,7 +100,9 @@ TY_HD uint32_t msm_windows(uint32_t c, bool centred) {
     const uint32_t w0 = (bits + c - 1) / c;
     return w0 + ((bits - c * (w0 - 1)) == c ? 1u : 0u);
 }
-void launch_srs_tables(uint32_t* pts, uint64_t len, uint32_t c, uint32_t T, hipStream_t s);
+// zbuf: srs_tables_scratch_bytes(len, T) bytes of scratch (0 bytes / null: every entry is normalised by itself)
+size_t srs_tables_scratch_bytes(uint64_t len, uint32_t T);
+void launch_srs_tables(uint32_t* pts, uint32_t* zbuf, uint64_t len, uint32_t c, uint32_t T, hipStream_t s);
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
                          uint32_t* order, uint32_t* heavy, uint32_t* tasks, bool hist_done, hipStream_t s);
 void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist516, uint32_t* heavy,
@@ -155,6 +157,11 @@ bool msm_rc2_ok(const RcShape& sh);
 void launch_msm_rc2_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* prow, uint32_t* pcol, uint32_t* out,
                            hipStream_t s);
 void launch_msm_rc_combine(const uint32_t* planes, const RcShape& sh, uint32_t* set_sums, hipStream_t s);
-void launch_srs_generate(const Fr& s, uint64_t start, uint64_t n, uint32_t* pts, hipStream_t st);
+// comb: the fixed-base table of G (srs_comb_bytes() bytes, filled once by launch_srs_comb)
+// divsteps inversion against the Fermat ladder on threads * per_thread residues; out: {mismatches, max rounds, calls}
+void launch_fq_inv_selftest(uint64_t seed, uint32_t threads, uint32_t per_thread, uint32_t* out, hipStream_t st);
+size_t srs_comb_bytes();
+void launch_srs_comb(uint32_t* comb, hipStream_t st);
+void launch_srs_generate(const Fr& s, uint64_t start, uint64_t n, const uint32_t* comb, uint32_t* pts, hipStream_t st);
 
 }  // namespace ty

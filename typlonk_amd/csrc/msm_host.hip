@@ -514,7 +514,13 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
     if (len) {
         Fr s;
         memcpy(s.v, secret, sizeof(s.v));
-        launch_srs_generate(s, start, (uint64_t)len, e.d_points, ctx->stream);
+        if (!ctx->srs_comb.p) {   // [j 2^(8w)] G, once per context
+            const int rc = ensure(ctx, ctx->srs_comb, srs_comb_bytes());
+            if (rc != TYPLONK_OK) return rc;
+            launch_srs_comb((uint32_t*)ctx->srs_comb.p, ctx->stream);
+            HIPCHK(hipGetLastError());
+        }
+        launch_srs_generate(s, start, (uint64_t)len, (const uint32_t*)ctx->srs_comb.p, e.d_points, ctx->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
@@ -522,6 +528,26 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
     const uint32_t id = ctx->next_srs++;
     ctx->srs[id] = e;
     *srs_id = id;
+    return TYPLONK_OK;
+}
+
+int typlonk_selftest_fq_inv(typlonk_ctx* ctx, uint64_t seed, size_t count, uint64_t* mismatches, uint32_t* max_rounds) {
+    if (!ctx || !mismatches) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    uint32_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 16));
+    DevGuard guard;
+    guard.add(d);
+    HIPCHK(hipMemsetAsync(d, 0, 16, ctx->stream));
+    const uint32_t threads = 1u << 16;
+    const uint32_t per = (uint32_t)((count + threads - 1) / threads);
+    if (per) launch_fq_inv_selftest(seed, threads, per, d, ctx->stream);
+    HIPCHK(hipGetLastError());
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *mismatches = h[0];
+    if (max_rounds) *max_rounds = h[1];
     return TYPLONK_OK;
 }
 
@@ -556,7 +582,18 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     DevGuard guard;
     guard.add(big);
     HIPCHK(hipMemcpyAsync(big, e.d_points, e.len * PT_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    launch_srs_tables(big, (uint64_t)e.len, window_bits, T, ctx->stream);
+    // scratch of the shared normalisation (one denominator per entry); without it -- allocation refused -- every entry is
+    // normalised by itself, as in rounds 1-4
+    uint32_t* zbuf = nullptr;
+    if (const size_t zb = srs_tables_scratch_bytes(e.len, T)) {
+        if (hipMalloc((void**)&zbuf, zb) != hipSuccess) {
+            (void)hipGetLastError();
+            zbuf = nullptr;
+        }
+    }
+    DevGuard zguard;
+    zguard.add(zbuf);
+    launch_srs_tables(big, zbuf, (uint64_t)e.len, window_bits, T, ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     guard.dismiss();
