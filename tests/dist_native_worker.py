@@ -76,21 +76,21 @@ def main():
     buf = ctx.alloc(n)
     buf.upload(scalars(n, 77))
     # ---- one MSM, the batch in pieces, the fold of caller-held points --------------------------------------------------------
-    out["msm"] = [pt(ctx.msm_sharded_devptr(sid, buf.devptr(), m)) for m in (n, n - 1, 1, 0)]
+    out["msm"] = [pt(ctx.msm_sharded_devptr(sid, buf.devptr, m)) for m in (n, n - 1, 1, 0)]
     ms = batch_lengths(n)
-    out["batch"] = [pt(p) for p in ctx.msm_sharded_batch_devptr(sid, [buf.devptr()] * len(ms), ms)]
-    part = ctx.msm_devptr(sid, buf.devptr(), n)            # this rank's partial sum, folded by hand
+    out["batch"] = [pt(p) for p in ctx.msm_sharded_batch_devptr(sid, [buf.devptr] * len(ms), ms)]
+    part = ctx.msm_devptr(sid, buf.devptr, n)            # this rank's partial sum, folded by hand
     out["fold"] = pt(ctx.comm_fold([part])[0])
     # ---- the failure path: rank 1 asks for more terms than the SRS has ---------------------------------------------------------
     try:
-        ctx.msm_sharded_devptr(sid, buf.devptr(), total + 1 if rank == 1 else n)
+        ctx.msm_sharded_devptr(sid, buf.devptr, total + 1 if rank == 1 else n)
         out["fail"] = "ok"
     except TyplonkError as e:
         out["fail"] = [e.code, str(e)]
-    out["fail_next"] = pt(ctx.msm_sharded_devptr(sid, buf.devptr(), n))
+    out["fail_next"] = pt(ctx.msm_sharded_devptr(sid, buf.devptr, n))
     # ... and in a batch: the whole group fails together
     try:
-        ctx.msm_sharded_batch_devptr(sid, [buf.devptr()] * 3, [n, total + 1 if rank == 1 else n, 5])
+        ctx.msm_sharded_batch_devptr(sid, [buf.devptr] * 3, [n, total + 1 if rank == 1 else n, 5])
         out["fail_batch"] = "ok"
     except TyplonkError as e:
         out["fail_batch"] = [e.code, str(e)]

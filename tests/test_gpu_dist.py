@@ -242,13 +242,13 @@ def test_native_exchange_with_world_N_on_one_gpu(built, tmp_path, world, log_n, 
         full = ctx.srs_generate(fr_mont_limbs(SECRET), n + 3)
         buf = ctx.alloc(n)
         buf.upload(scalars(n, 77))
-        want_msm = [pt(ctx.msm_devptr(full, buf.devptr(), m)) for m in (n, n - 1, 1, 0)]
+        want_msm = [pt(ctx.msm_devptr(full, buf.devptr, m)) for m in (n, n - 1, 1, 0)]
         ms = batch_lengths(n)
-        want_batch = [pt(p) for p in ctx.msm_batch_devptr(full, [buf.devptr()] * len(ms), ms)]
+        want_batch = [pt(p) for p in ctx.msm_batch_devptr(full, [buf.devptr] * len(ms), ms)]
         chain = SquaringChain(ctx, log_n)
         pr = ctx.prove_native(full, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
         ident = pt((np.zeros(12, dtype=np.uint64), 1))
-        ident[0][6:] = [int(v) for v in ctx.msm_devptr(full, buf.devptr(), 0)[0][6:]]     # the (0, 1, inf) encoding
+        ident[0][6:] = [int(v) for v in ctx.msm_devptr(full, buf.devptr, 0)[0][6:]]     # the (0, 1, inf) encoding
         for r, o in enumerate(ranks):
             assert o["msm"] == want_msm and o["batch"] == want_batch and o["fold"] == want_msm[0], r
             assert o["fail_next"] == want_msm[0], r
