@@ -123,6 +123,7 @@ struct typlonk_buf {
 //   TYPLONK_MSM_LANES     lanes per bucket of the accumulation (1, 2, 4, 8, 16; 0 = by bucket load)
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
 //   TYPLONK_NTT_FR30      0 | 1 | 2: the 9 x 30-bit butterflies never / where they measure faster / always
+//   TYPLONK_PROVER_PIPE   0 | 1: round 3's nine commitments queued as in rounds 1-4 / behind one fence (prover_round3_core)
 // (TYPLONK_RCCL_LIB, read by comm.hip, names the RCCL library to load.)
 struct typlonk_ctx {
     int device = 0;
@@ -157,6 +158,7 @@ struct typlonk_ctx {
     // 0.419 -> 0.464 ms per MSM -- so the switch sits below the shard size; from 2^19 on the chain is never worse and
     // 2^20 needs it.  -1 = by term count (MSM_CHAIN_MIN_TERMS), 0 / 1 = TYPLONK_MSM_CHAIN.
     int msm_chain = -1;
+    bool prover_pipe = true;       // TYPLONK_PROVER_PIPE (A/B switch of the round-5 queueing fix, prover_round3_core)
     int msm_chunks = 0;            // chunks of a stand-alone MSM (0 = choose by length)
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_rc4 = false;          // always the four-launch row/column reduction

@@ -615,6 +615,16 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
         const Fr* polys[9] = {p->q[0], p->q[1], p->q[2], p->q[3], p->q[4], p->q[5], p->t, p->t + n, p->t + 2 * n};
         const size_t m[9] = {n - 1, n - 1, n - 1, n - 1, n - 1, n - 1, n, n, n > 3 ? n - 3 : 0};
         q.set_first_lane(0);  // the context's stream has nothing left to do but commit
+        // All nine polynomials exist once what is queued on the context's stream NOW has run: the lanes wait for this
+        // mark, not for "everything on the context's stream at submit time" -- which, with the context's stream itself a
+        // lane, included the whole MSM submitted to it just before.  (Rounds 1-4: commitments 4 and 5 started their sorts
+        // only when commitment 3 had finished, and 7 and 8 after 6: two stretches of 1.2 ms with no accumulation in
+        // flight, profiles/r04_prove_timeline.txt 23.1-24.4 and 30.6-31.9 ms.)
+        if (ctx->prover_pipe) {
+            if (!ctx->batch_fence) HIPCHK(hipEventCreateWithFlags(&ctx->batch_fence, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ctx->batch_fence, ctx->stream));
+            q.fence = ctx->batch_fence;
+        }
         for (int k = 0; k < 9 && !rc; ++k) rc = q.submit(polys[k], m[k], xy[k], inf + k);
         {
             const int r = q.wait_all();
