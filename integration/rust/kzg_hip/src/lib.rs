@@ -27,9 +27,27 @@ use std::ptr;
 pub type G1Point = G1Affine;
 pub type Poly = DensePolynomial<Fr>;
 
-/// One HIP device + stream + workspaces (`typlonk_ctx`).  Not `Sync`: one host thread per context (typlonk.h).
+/// One HIP device + stream + workspaces (`typlonk_ctx`).  It holds a raw pointer, so it is neither `Send` nor `Sync`
+/// -- and therefore neither is anything that embeds it (`kzg::srs::Srs`, `plonk::CompiledCircuit` after the patches):
+/// one host thread per context, as typlonk.h requires.  A program that proves on several threads gives each thread its
+/// own `Backend::shared` (the registry is thread-local) or wraps the calls in its own lock.
 pub struct Backend {
     ctx: *mut ffi::TyplonkCtx,
+}
+
+thread_local! {
+    // Backend::shared: one context per (thread, device ordinal), created on first use
+    static SHARED: std::cell::RefCell<Vec<(i32, std::rc::Rc<Backend>)>> = std::cell::RefCell::new(Vec::new());
+}
+
+/// the device this process works on: `TYPLONK_DEVICE` (default 0).  One process per GPU: the launcher sets it per rank.
+pub fn device_from_env() -> i32 {
+    std::env::var("TYPLONK_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0)
+}
+/// fixed-base window tables for an uploaded SRS are opt-in (`TYPLONK_TABLES=1`): they multiply the SRS's footprint in
+/// HBM by 13-17 and only pay when many commitments follow (a prover; not a one-off `commit`)
+pub fn tables_from_env() -> bool {
+    std::env::var("TYPLONK_TABLES").map(|v| v != "0" && !v.is_empty()).unwrap_or(false)
 }
 
 /// An SRS resident in HBM (`typlonk_srs_load`), with the fixed-base tables the library chooses for its length.
@@ -94,9 +112,25 @@ impl Backend {
         }
     }
 
+    /// The context of this thread for `device_ordinal`, created on first use and shared by every `Srs` /
+    /// `CompiledCircuit` of the thread: `Srs::from_secret` must not open a context (streams, workspaces, an SRS upload)
+    /// per call.
+    pub fn shared(device_ordinal: i32) -> std::rc::Rc<Backend> {
+        SHARED.with(|reg| {
+            let mut reg = reg.borrow_mut();
+            if let Some((_, b)) = reg.iter().find(|(d, _)| *d == device_ordinal) {
+                return b.clone();
+            }
+            let b = std::rc::Rc::new(Backend::new(device_ordinal));
+            reg.push((device_ordinal, b.clone()));
+            b
+        })
+    }
+
     // ---- SRS ------------------------------------------------------------------------------------------------------
-    /// once per `Srs` (kzg/src/srs.rs:30-34): copy the G1 powers to HBM and let the library build its tables
-    pub fn upload_srs(&self, g1: &[G1Point]) -> SrsHandle {
+    /// once per `Srs` (kzg/src/srs.rs:30-34): copy the G1 powers to HBM; `tables`: also build the fixed-base window
+    /// tables (`precompute_tables`)
+    pub fn upload_srs(&self, g1: &[G1Point], tables: bool) -> SrsHandle {
         let mut xy = Vec::with_capacity(g1.len() * 12);
         let mut inf = Vec::with_capacity(g1.len());
         for p in g1 {
@@ -106,18 +140,29 @@ impl Backend {
         }
         let mut id = 0u32;
         self.check(unsafe { ffi::typlonk_srs_load(self.ctx, xy.as_ptr(), inf.as_ptr(), g1.len(), &mut id) });
-        // speed only, results unchanged; 0 = window chosen by length (nothing below TYPLONK_TABLES_AUTO_MIN_LEN points)
-        self.check(unsafe { ffi::typlonk_srs_precompute(self.ctx, id, 0) });
-        SrsHandle { id, len: g1.len() }
+        let h = SrsHandle { id, len: g1.len() };
+        if tables {
+            self.precompute_tables(h);
+        }
+        h
+    }
+
+    /// `typlonk_srs_precompute`: speed only, results unchanged; the window is chosen by length (nothing at all below
+    /// TYPLONK_TABLES_AUTO_MIN_LEN points).  13-17 copies of the SRS in HBM.
+    pub fn precompute_tables(&self, srs: SrsHandle) {
+        self.check(unsafe { ffi::typlonk_srs_precompute(self.ctx, srs.id, 0) });
     }
 
     /// `Srs::from_secret` on the device: `[s^(start + i)] G`, i < len (each GPU of a node builds only its shard)
-    pub fn generate_srs(&self, secret: &Fr, start: u64, len: usize) -> SrsHandle {
+    pub fn generate_srs(&self, secret: &Fr, start: u64, len: usize, tables: bool) -> SrsHandle {
         let s = fr_limbs(secret);
         let mut id = 0u32;
         self.check(unsafe { ffi::typlonk_srs_generate(self.ctx, s.as_ptr(), start, len, &mut id) });
-        self.check(unsafe { ffi::typlonk_srs_precompute(self.ctx, id, 0) });
-        SrsHandle { id, len }
+        let h = SrsHandle { id, len };
+        if tables {
+            self.precompute_tables(h);
+        }
+        h
     }
 
     // ---- MSM seam: the body of KzgScheme::evaluate_in_s (kzg/src/lib.rs:41-54) -------------------------------------

@@ -174,11 +174,15 @@ def test_native_rccl_exchange_behind_the_c_abi(built):
         ctx.close()
 
 
+@pytest.mark.slow
 def test_config5_eight_ranks_prove_at_2_22_batched_and_six_openings():
     """BASELINE config 5 as written, on the one GPU of the test box: the 2^22-row circuit, full prove() with the quotient's
     2^24-point coset NTTs, every MSM index-sharded over EIGHT ranks (gloo; 2^19-point SRS shards with the library's own
     table choice), in the reference's proof shape AND with batched KZG openings -- each equal, element for element, to
     the proof of one rank holding the whole SRS, r(zeta) = 0; plus short MSMs whose range is empty on most ranks."""
+    from conftest import need_resources
+
+    need_resources(host_gib=24, hbm_gib=60)     # eight ranks: 2^19-point shards with tables + a 2^24-point quotient workspace each
     env = dict(os.environ, LOG_N="22", TABLES="auto")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_prove_worker.py")]

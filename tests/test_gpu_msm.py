@@ -557,14 +557,17 @@ def test_chunked_pipeline_gives_identical_results(built, chunks, monkeypatch):
         c2.close()
 
 
+@pytest.mark.slow
 def test_more_than_2_23_terms_takes_the_counting_sort_fallback(ctx):
     """The segmented sort indexes terms with 23 bits; a longer MSM falls back to the global counting sort (msm_host.hip
     msm_enqueue -- the path has no switch of its own since round 4, so this is the test that reaches it): 2^23 + 5 terms
     over [s^i]G against commit(p) == [p(s)]G (kzg/src/lib.rs:102-105), with the ragged lengths m - 1 and m - 3, and a
     chunk-sized control below the limit through the ordinary path over the same SRS."""
     import torch
+    from conftest import need_resources
     from oracle import coracle as CO
 
+    need_resources(host_gib=3, hbm_gib=6)
     m = (1 << 23) + 5
     s_limbs = np.array(O.fr_to_mont_limbs(2), dtype=np.uint64)
     sid = ctx.srs_generate(s_limbs, m)

@@ -170,14 +170,17 @@ def test_both_butterfly_kernels_give_the_c_oracles_words(built, mode, monkeypatc
         c2.close()
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("log_n", [26, 27])
 def test_beyond_the_full_table_limit_vs_c_oracle(ctx, log_n):
     """typlonk_ntt_fr accepts every two-adic size; above 2^24 points the inter-pass twiddles are composed from two-level
     tables instead of read from a full table, and four passes are needed.  Whole-vector equality with the C restatement
     (its OpenMP form: the one-thread form takes a minute here) at 2^26 and 2^27 (a 4-GiB vector), forward, and the
     inverse round trip."""
+    from conftest import need_resources
     from oracle import coracle as CO
 
+    need_resources(host_gib=5 * (32 << log_n) / (1 << 30) + 2, hbm_gib=3 * (32 << log_n) / (1 << 30) + 2)
     x = rand_limbs(2000 + log_n, 1 << log_n)
     f = ctx.ntt(x, log_n)
     assert (f == CO.ntt(x, log_n, threads=0)).all()

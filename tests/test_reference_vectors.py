@@ -100,6 +100,32 @@ def test_kzg_commit_open_srs_and_msm(vec):
     assert (got == want).all() and ginf == winf
 
 
+def test_srs_slice_and_into_affine(vec, built):
+    """Srs::from_secret at a non-zero start (kzg/src/srs.rs:15-24) and ark-ec's Jacobian -> affine normalisation
+    (x = X / Z^2, y = Y / Z^3: the per-term `into()` of kzg/src/lib.rs:50) -- against the oracle, and the field inversion
+    under it against the product's THREE inversions (host Euclid, Fermat ladder, the device's divsteps; host shim)"""
+    import ctypes
+
+    from helpers import u32p
+
+    if "srs_slice" not in vec:
+        pytest.skip("vector file predates round 5 (no srs_slice / into_affine): re-run tools/rust_vectors")
+    sl = vec["srs_slice"]
+    s = _fr(sl["secret"])
+    start = int(sl["start"])
+    assert [_pt(p) for p in sl["points"]] == O.srs_from_secret(s, start + len(sl["points"]))[start:start + len(sl["points"])]
+    ia = vec["into_affine"]
+    x, y, z = (O.fq_from_mont_limbs(_limbs(ia[k])) for k in ("x", "y", "z"))
+    zi = pow(z, -1, O.P)
+    assert _pt(ia["affine"]) == (x * zi * zi % O.P, y * zi * zi * zi % O.P)
+    shim = ctypes.CDLL(os.path.join(ROOT, "tests", "cpp", "libff_host_shim.so"))
+    zl = np.array(_limbs(ia["z"]), dtype=np.uint64)
+    o = np.zeros(6, dtype=np.uint64)
+    shim.shim_fq_inv(u32p(zl), u32p(o))
+    assert O.fq_from_mont_limbs([int(v) for v in o]) == zi
+    assert 0 <= shim.shim_fq_inv_divsteps_agree(u32p(zl), 0) <= 37      # divsteps == Fermat == Euclid on this Z
+
+
 def test_radix2_domain_transforms(vec):
     """ark-poly Radix2EvaluationDomain fft / ifft / coset_fft, natural order, against the oracle's O(n^2) DFT and NTT"""
     f = vec["fft"]
@@ -121,6 +147,14 @@ def test_hip_path_on_the_reference_vectors(vec, ctx):
     want, winf = _pt_abi(m["commitment"])
     assert (got == want).all() and ginf == winf
     ctx.srs_free(sid)
+    if "srs_slice" in vec:       # typlonk_srs_generate at a non-zero start (comb + divsteps inversion on the device)
+        sl = vec["srs_slice"]
+        sid = ctx.srs_generate(np.array(_limbs(sl["secret"]), dtype=np.uint64), len(sl["points"]), start=int(sl["start"]))
+        xy, inf = ctx.srs_download(sid)
+        for i, p in enumerate(sl["points"]):
+            want, winf = _pt_abi(p)
+            assert (xy[i] == want).all() and int(inf[i]) == winf
+        ctx.srs_free(sid)
     f = vec["fft"]
     data = np.array([_limbs(c) for c in m["coeffs"]], dtype=np.uint64)
     assert (ctx.ntt(data, 3) == np.array([_limbs(x) for x in f["fft8_of_msm8_coeffs"]], dtype=np.uint64)).all()

@@ -35,6 +35,12 @@ secret = 0x0123456789abcdef0123456789abcdef
 rng = T.StdRng.seed_from_u64(7)
 coeffs = [O.fr_from_mont_limbs([int(v) for v in T.fr_rand(rng)]) for _ in range(8)]
 out["msm8"] = {"secret": fr(secret), "coeffs": [fr(c) for c in coeffs], "commitment": pt(O.kzg_commit(O.srs_from_secret(secret, 8), coeffs))}
+srs3 = O.srs_from_secret(secret, 40)
+out["srs_slice"] = {"secret": fr(secret), "start": 30, "points": [pt(p) for p in srs3[30:36]]}
+aff = O.g1_add(O.g1_mul(G, 2 * 0x1234567), O.g1_mul(G, coeffs[0]))
+z = 0x1F2E3D4C5B6A79880112233445566778899AABBCCDDEEFF % O.P
+out["into_affine"] = {"x": hx(O.fq_to_mont_limbs(aff[0] * z * z % O.P)), "y": hx(O.fq_to_mont_limbs(aff[1] * z * z * z % O.P)),
+                      "z": hx(O.fq_to_mont_limbs(z)), "affine": pt(aff)}
 v = [1, 2, 3, 4]
 out["fft"] = {"input": [fr(x) for x in v], "fft4": [fr(x) for x in O.ntt(v, 2)], "ifft4": [fr(x) for x in O.ntt(v, 2, inverse=True)],
               "fft8_of_msm8_coeffs": [fr(x) for x in O.ntt(coeffs, 3)], "coset_fft8_of_msm8_coeffs": [fr(x) for x in O.ntt(coeffs, 3, coset=7)],

@@ -11,6 +11,10 @@
 //!   srs                      kzg/src/srs.rs:15-34
 //!   fft / ifft               ark-poly Radix2EvaluationDomain as reached from plonk/src/proof.rs:50, 115
 //!   msm8                     evaluate_in_s on an 8-term polynomial with a large secret
+//!   srs_slice                kzg/src/srs.rs:15-24 at a NON-ZERO start: powers 30..36 of the large secret (what
+//!                            typlonk_srs_generate(start = 30) must reproduce -- fixed-base comb + divsteps inversion)
+//!   into_affine              kzg/src/lib.rs:50 / srs.rs:20: the per-term `into()` of a Jacobian point with Z != 1
+//!                            (ark-ec 0.3 `From<GroupProjective> for GroupAffine`: x = X / Z^2, y = Y / Z^3)
 //! `plonk::proof::challenges` is a private module, so the generator's call sequence is issued here directly against
 //! the same crates.
 use ark_bls12_381::{Fr, G1Affine};
@@ -142,6 +146,15 @@ fn emit_reference_vectors() {
         g1_json(c8.inner())
     )
     .unwrap();
+
+    // Srs::from_secret at a non-zero start, and one into_affine of a projective point whose Z is not 1
+    let srs3 = Srs::from_secret(secret, 40);
+    writeln!(out, "\"srs_slice\": {{\"secret\":{},\"start\":30,\"points\":{}}},", fr_json(&secret),
+             list(srs3.g1_ref()[30..36].iter().map(g1_json).collect())).unwrap();
+    let j = g.mul(Fr::from(0x1234567u64)).double() + g.mul(coeffs[0]);   // GroupProjective (Jacobian), Z != 1
+    let ja = j.into_affine();
+    writeln!(out, "\"into_affine\": {{\"x\":{},\"y\":{},\"z\":{},\"affine\":{}}},", hex_limbs(&j.x.0 .0), hex_limbs(&j.y.0 .0),
+             hex_limbs(&j.z.0 .0), g1_json(&ja)).unwrap();
 
     // ark-poly radix-2 transforms, natural order in and out
     let dom = GeneralEvaluationDomain::<Fr>::new(4).unwrap();

@@ -30,6 +30,9 @@ struct Fr30 {
     uint32_t v[9];
 };
 constexpr uint32_t FR30_MASK = 0x3fffffffu;
+// the most butterfly stages one pass may run on this form: the value bounds below (and fr30_reduce_lazy's x_8 < 2^29) are
+// derived for k <= 10; ntt_run (ntt_host.hip) sends a plan with a longer pass to the 8 x 32-bit kernel
+constexpr uint32_t FR30_MAX_STAGES = 10;
 
 TY_HD constexpr uint32_t fr30_r(int i) {
     constexpr uint32_t t[9] = {0x1u, 0x3ffffffcu, 0x3fe5bfefu, 0x2f6900bfu, 0x21d80553u, 0x27602026u, 0x17d48333u, 0x29d4ca67u, 0x73edu};
@@ -126,7 +129,8 @@ __device__ __forceinline__ Fr fr30_to_canonical(const Fr30& a) {
     fe_reduce_once(o);
     return o;
 }
-// x - q r for a small q (< 2^14), limb-wise with a signed running carry; exact limbs out.  Needs x >= q r.
+// x - q r for a small q (< 2^15: fr30_reduce_lazy passes x_8 / 0x73ee <= 18089), limb-wise with a signed running carry;
+// exact limbs out.  Needs x >= q r.
 __device__ __forceinline__ Fr30 fr30_sub_qr(const Fr30& x, uint32_t q) {
     Fr30 o;
     int64_t acc = 0;

@@ -2,6 +2,7 @@
 // Part of the host driver of include/typlonk.h (see host.hpp for the shared state).  There is deliberately no CPU compute
 // fallback: without a HIP device typlonk_init fails with TYPLONK_ERR_NO_DEVICE.
 #include "host.hpp"
+#include "fr30.hpp"
 
 using namespace ty;
 using namespace tyh;
@@ -302,6 +303,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     // of them must exist as a full table; if one cannot be built (size, memory) the transform runs on the 8 x 32 kernel.
     Table sub30[4]{}, tw30[4]{}, pre30{}, post30{}, scale30{};
     bool f30 = want30;
+    for (uint32_t p = 0; p < P; ++p) f30 = f30 && ks[p] <= FR30_MAX_STAGES;   // the bounds of fr30.hpp hold for k <= 10
     if (f30) {
         const Fr c14 = fr_from_u64(1u << 14);
         int rc = TYPLONK_OK;

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
             const uint64_t o = obase + t + a.out_stride * kk;
             if (a.post_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.post_full + o)));
             else if (a.scale) x = fr30_mul(x, fr30_unpack(ntt_ld(a.scale)));
-            else x = fr30_reduce_lazy(x);   // no factor to fold the reduction into: two quotient estimates instead of a multiplication
+            else x = fr30_reduce_lazy(x);   // no factor to fold the reduction into: one quotient estimate instead of a multiplication
             ntt_st(a.out + o, fr30_to_canonical(x));
         }
     };
@@ -340,7 +340,13 @@ static bool ntt_raise_lds(const void* kernel, int which) {
     if (state[which][dev] < 0) (void)hipGetLastError();
     return state[which][dev] > 0;
 }
-bool ntt_big_tiles_available() { return ntt_raise_lds(reinterpret_cast<const void*>(ntt_pass_kernel), 0); }
+// (both kernels: which of the two runs a 2^20 transform is decided later, by the tables that could be built -- the plan
+// must be launchable either way, so a refusal for one of them sends the planner back to 1024-element tiles for both)
+bool ntt_big_tiles_available() {
+    const bool a = ntt_raise_lds(reinterpret_cast<const void*>(ntt_pass_kernel), 0);
+    const bool b = ntt_raise_lds(reinterpret_cast<const void*>(ntt_pass30_kernel), 1);
+    return a && b;
+}
 
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s) {
     if (lds_bytes > 64 * 1024) (void)ntt_raise_lds(reinterpret_cast<const void*>(ntt_pass_kernel), 0);
