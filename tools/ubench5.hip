@@ -370,6 +370,7 @@ int main(int argc, char** argv) {
     CHK(hipGetDeviceProperties(&prop, 0));
     printf("device %s, %d CUs, nominal %d MHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
     const bool only_b = argc > 1 && strcmp(argv[1], "affine") == 0;
+    const bool only_a = argc > 1 && strcmp(argv[1], "inv") == 0;
 
     double mul_w[4] = {0, 0, 0, 0};
     if (!only_b) {
@@ -412,6 +413,7 @@ int main(int argc, char** argv) {
         CHK(hipFree(d_rounds));
     }
 
+    if (only_a) return 0;
     // ---- (b) ----
     printf("\n(b) batched-affine bucket round against the XYZZ mixed addition (chip-wide, HIP events)\n");
     const uint32_t n = (uint32_t)prop.multiProcessorCount * 256 * 6;   // six workgroups of 256 per CU (1, 2 or 3 resident at a time)

@@ -570,29 +570,45 @@ constexpr uint32_t FQ30_PINV = 0x00030003u;   // p^-1 mod 2^30
 
 // 30 divsteps on the low words; eta = -delta.  Only bit 0 of g is ever inspected and step i sees input bits <= i, so the
 // two spare bits of the 32-bit registers may hold anything.  t = {u, v, q, r}.
+//
+// The step is linear in the matrix rows -- negate, add, double -- so a row travels as ONE register, u + v 2^16 as a plain
+// integer (and q + r 2^16): six instructions per step for the matrix instead of twelve.  A packed row is exact while
+// |u|, |v| < 2^15, so the 30 steps run as three groups of ten (entries <= 2^10), and the group matrices are multiplied
+// together (4 multiplications + 4 multiply-adds on 32-bit words per product; |u| + |v| <= 2^30 at the end).
+// Round 5: 780 -> 640 instructions for the 30 steps.
 TY_HD int32_t fq30_divsteps30(int32_t eta, uint32_t f, uint32_t g, int32_t (&t)[4]) {
-    uint32_t u = 1, v = 0, q = 0, r = 1;
+    int32_t mu = 1, mv = 0, mq = 0, mr = 1;               // the matrix of the groups done so far
+#pragma unroll 1
+    for (int grp = 0; grp < 3; ++grp) {
+        uint32_t a = 1u, b = 1u << 16;                    // rows (u, v) = (1, 0) and (q, r) = (0, 1)
 #pragma unroll
-    for (int i = 0; i < 30; ++i) {
-        uint32_t c1 = (uint32_t)(eta >> 31);              // delta > 0
-        const uint32_t c2 = 0u - (g & 1u);                // g odd
-        // g <- g +- f (minus when delta > 0), likewise the second matrix row
-        g += ((f ^ c1) - c1) & c2;
-        q += ((u ^ c1) - c1) & c2;
-        r += ((v ^ c1) - c1) & c2;
-        c1 &= c2;                                         // swap: delta > 0 and g odd
-        eta = (int32_t)(((uint32_t)eta ^ c1) + ~c1);      // swap: -eta - 1 = ~eta; else eta - 1
-        f += g & c1;                                      // swap: f <- old g
-        u += q & c1;
-        v += r & c1;
-        g >>= 1;
-        u += u;                                           // the f-row is scaled instead of halving the g-row
-        v += v;
+        for (int i = 0; i < 10; ++i) {
+            uint32_t c1 = (uint32_t)(eta >> 31);          // delta > 0
+            const uint32_t c2 = 0u - (g & 1u);            // g odd
+            // g <- g +- f (minus when delta > 0), likewise the second matrix row
+            g += ((f ^ c1) - c1) & c2;
+            b += ((a ^ c1) - c1) & c2;
+            c1 &= c2;                                     // swap: delta > 0 and g odd
+            eta = (int32_t)(((uint32_t)eta ^ c1) + ~c1);  // swap: -eta - 1 = ~eta; else eta - 1
+            f += g & c1;                                  // swap: f <- old g
+            a += b & c1;
+            g >>= 1;
+            a += a;                                       // the f-row is scaled instead of halving the g-row
+        }
+        // unpack: low half sign-extended, the rest is the high half exactly
+        const int32_t u = (int32_t)(a << 16) >> 16, v = (int32_t)(a - (uint32_t)u) >> 16;
+        const int32_t q = (int32_t)(b << 16) >> 16, r = (int32_t)(b - (uint32_t)q) >> 16;
+        // (this group) x (the groups before it)
+        const int32_t nu = u * mu + v * mq, nv = u * mv + v * mr, nq = q * mu + r * mq, nr = q * mv + r * mr;
+        mu = nu;
+        mv = nv;
+        mq = nq;
+        mr = nr;
     }
-    t[0] = (int32_t)u;
-    t[1] = (int32_t)v;
-    t[2] = (int32_t)q;
-    t[3] = (int32_t)r;
+    t[0] = mu;
+    t[1] = mv;
+    t[2] = mq;
+    t[3] = mr;
     return eta;
 }
 // acc += a * b on signed 32-bit factors: ONE v_mad_i64_i32 on the device.  The limbs below the top one are known to be
