@@ -47,7 +47,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     env = dict(os.environ, TYPLONK_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "18", "--steps", "3",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "20", "--steps", "3",
                         "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     out = [l for l in r.stdout.splitlines() if l.strip()]
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -57,6 +57,13 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert d["parity"]["full_commit_identity"] is True
     assert d["rccl_world"] == 0 and "gloo" in d["exchange"] and "ranks_share_gpu" in d
     assert d["msm_batch"]["ms_per_msm"] > 0 and d["prove_sharded_ms"] > 0 and d["prove_sharded_batched_ms"] > 0
+    # the three modes side by side, each against this round's one-GPU record, plus the one-GPU projection for this N
+    # (bench.py, add_scaling_context): a SCALE record is readable without re-deriving DESIGN.md section 6
+    sc = d["scaling_vs_one_gpu"]
+    assert sc["standalone"] > 0 and sc["batched"] > 0 and sc["prove"] > 0 and d["scaling_batched"] == sc["batched"]
+    assert "batched" in sc["claim"] and d["one_gpu_reference"]["source"].startswith("profiles/r0")
+    exp = d["expected_from_1gpu"]
+    assert exp["speedup"]["batched_msms"] > exp["speedup"]["one_msm"] > 1 and "shard_latency" in exp["source"]
 
 
 def test_one_rank_through_rccl_all_gather():
