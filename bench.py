@@ -133,7 +133,7 @@ class Section:
 # ---- N > 1: what the line is read against (review of round 4) -----------------------------------------------------------
 # A scaling record of this bench has three modes next to each other -- ONE stand-alone MSM per step (`value`, the headline),
 # nine MSMs in flight per call (`msm_batch`, how prove() issues its commitments) and the whole sharded prove() -- and the
-# north-star's ">= 6x at 8 GPUs" is claimed for the batched mode only (DESIGN.md section 6: a stand-alone 2^17-term MSM has a
+# north-star's ">= 6x at 8 GPUs" is claimed for the batched mode only (DESIGN.md section 7: a stand-alone 2^17-term MSM has a
 # latency floor of ~0.54 ms -> ~4.5-4.8x).  So that a record can be read without re-deriving that, every N > 1 line
 # carries (a) the one-GPU figures of this round it should be divided into, from the committed one-GPU record, and (b) the
 # projection made on ONE GPU acting as rank 0 of N (tools/shard_latency.py: real kernels on a 1/N shard, the exchange on a

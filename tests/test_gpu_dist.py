@@ -58,7 +58,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert d["rccl_world"] == 0 and "gloo" in d["exchange"] and "ranks_share_gpu" in d
     assert d["msm_batch"]["ms_per_msm"] > 0 and d["prove_sharded_ms"] > 0 and d["prove_sharded_batched_ms"] > 0
     # the three modes side by side, each against this round's one-GPU record, plus the one-GPU projection for this N
-    # (bench.py, add_scaling_context): a SCALE record is readable without re-deriving DESIGN.md section 6
+    # (bench.py, add_scaling_context): a SCALE record is readable without re-deriving DESIGN.md section 7
     sc = d["scaling_vs_one_gpu"]
     assert sc["standalone"] > 0 and sc["batched"] > 0 and sc["prove"] > 0 and d["scaling_batched"] == sc["batched"]
     assert "batched" in sc["claim"] and d["one_gpu_reference"]["source"].startswith("profiles/r0")

@@ -556,7 +556,7 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     auto it = ctx->srs.find(srs_id);
     if (it == ctx->srs.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown srs id");
     if (window_bits == 0) {
-        // auto: 15 below 2^16 points, 17 below 2^19, else 20 (measured best: DESIGN.md sections 4, 6;
+        // auto: 15 below 2^16 points, 17 below 2^19, else 20 (measured best: HISTORY.md sections 4, 6;
         // profiles/r04_tables_small_sizes.txt) -- and nothing at all for an SRS shorter
         // than 2^14 points: 2^16 buckets (sort, reduction, heavy-bucket launch) for a handful of terms would be slower
         // than the plain path, whose window follows the length

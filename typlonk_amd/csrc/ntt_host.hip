@@ -257,7 +257,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         scratch = (Fr*)ctx->ntt_scratch.p;
     }
 
-    // measured: the 9 x 30-bit kernel is 9-12 % faster up to 2^19; at 2^20 the two-pass 4096-element
+    // measured (HISTORY.md section 5): the 9 x 30-bit kernel is 9-12 % faster up to 2^19; at 2^20 the two-pass 4096-element
     // tiles of the 8 x 32 kernel win, and from 2^21 on the 36-B LDS elements cost a workgroup per CU (3 instead of 4)
     // and a forward transform pays one extra reducing multiplication per element: mode 1 (default) stops at 2^19
     // Round 3 (radix-4 groups in both kernels, profiles/r03_ntt_fr30_modes.txt): an INVERSE transform is 4-9 % faster on the
