@@ -115,10 +115,14 @@ int typlonk_srs_len(typlonk_ctx* ctx, uint32_t srs_id, size_t* len);
  *                            full coefficient vector(s) and gets the full sum(s) (collective).
  * typlonk_prove on a context with a communicator and an SRS shard folds the commitments of every round itself, so
  * all ranks hash identical points, squeeze identical challenges and return the identical proof.
- * Failure on one rank: the *_sharded_* entry points and typlonk_prove still join the collective of the step that
- * failed, with flagged records, so that rank returns its own error code and every other rank TYPLONK_ERR_COMM
- * (typlonk_last_error names the rank) -- nobody is left waiting; the communicator stays usable.  The exchange buffers
- * are allocated by typlonk_comm_init; a fold never allocates (more than 32 points go through in pieces).
+ * Failure on one rank: a member of a communicator never leaves between "decided to fold" and the collective.  The
+ * *_sharded_* entry points, typlonk_comm_fold_g1 and typlonk_prove join the collective of the step that failed with
+ * flagged records -- whether the failure is the local MSM / prover round, a bad argument (a null output, m > len) or the
+ * staging copy of the records itself (the send buffer is kept poisoned except between a successful copy and the
+ * all-gather) -- so that rank returns its own error code and every other rank TYPLONK_ERR_COMM (typlonk_last_error
+ * names the rank); nobody is left waiting and the communicator stays usable.  The exchange buffers are allocated by
+ * typlonk_comm_init BEFORE it joins ncclCommInitRank (a rank that cannot allocate never becomes a member); a fold never
+ * allocates (more than 32 points go through in pieces).  Exercised with 2 and 8 ranks: tests/test_gpu_dist.py.
  *   typlonk_comm_available   1 if librccl can be loaded in this process (TYPLONK_RCCL_LIB names it, default: the SONAME
  *                            librccl.so.1), else 0.  NOT collective: ranks agree on it BEFORE the collective
  *                            typlonk_comm_init, in which a rank that cannot load the library would leave the others waiting. */

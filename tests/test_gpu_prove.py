@@ -390,6 +390,36 @@ def test_native_prove_equals_the_round_by_round_flow(ctx, log_n):
     ctx.srs_free(sid)
 
 
+@pytest.mark.parametrize("pipe", ["0", "1"])
+def test_round3_queueing_switch_does_not_change_a_bit(built, monkeypatch, pipe):
+    """TYPLONK_PROVER_PIPE: round 3's nine commitments behind one fence (round 5, the default) or queued as rounds 1-4
+    did -- scheduling only: the proof of a 2^14-row squaring chain over a table-mode SRS is the same, element for element,
+    as the one the default context of this process produces"""
+    import typlonk_amd
+    from typlonk_amd.circuits import SquaringChain
+
+    monkeypatch.setenv("TYPLONK_PROVER_PIPE", pipe)
+    log_n = 14
+    proofs = []
+    for fresh in (True, False):
+        if not fresh:
+            monkeypatch.delenv("TYPLONK_PROVER_PIPE")
+        c2 = typlonk_amd.Context(0)
+        try:
+            sid = c2.srs_generate(_limbs(0xFACE), (1 << log_n) + 3)
+            c2.srs_precompute(sid, 0)
+            chain = SquaringChain(c2, log_n)
+            proofs.append(c2.prove_native(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets))
+        finally:
+            c2.close()
+    a, b = proofs
+    same = lambda x, y: bool((np.asarray(x[0]) == np.asarray(y[0])).all() and int(x[1]) == int(y[1]))   # noqa: E731
+    for key in ("commit", "t_commit", "witness"):
+        assert all(same(x, y) for x, y in zip(a[key], b[key])), key
+    assert same(a["z_commit"], b["z_commit"]) and all((x == y).all() for x, y in zip(a["evals"], b["evals"]))
+    assert not a["evals"][5].any()
+
+
 def test_config5_prove_at_2_22_both_shapes(ctx):
     """BASELINE config 5's size, n = 2^22 (quotient domain 2^24): a full prove() in both proof shapes on one GPU.
     r(zeta) = 0; the wire commitments equal [p(s)]G with p = iNTT(wire column) evaluated by the C oracle (the reference's
