@@ -293,6 +293,8 @@ def main() -> None:
     ap.add_argument("--msm-only", action="store_true",
                     help="only the timed MSM loop and its roofline (the command the rocprofv3 summaries "
                          "profiles/r0x_kernel_stats_bench_msm_only.csv are taken from)")
+    ap.add_argument("--no-prove-2-22", action="store_true",
+                    help="skip the extra 2^22-row prove() (BASELINE config 5's size) the default 2^20 run reports next to the headline")
     ap.add_argument("--no-sharded-prove", action="store_true",
                     help="N > 1: skip the extra measurement of prove() with every MSM sharded over the ranks")
     ap.add_argument("--tables", default="auto",
@@ -509,6 +511,9 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
             bench_prove_sequence(ctx, sh, n, log_n, device, result)
         with Section(result, "prove"):
             bench_prove(ctx, sh, log_n, result)
+        if log_n == 20 and not args.no_prove_2_22:
+            with Section(result, "prove_2_22"):
+                bench_prove_2_22(dev_index, result)
         if not args.no_cpu_baseline:
             with Section(result, "cpu_baseline"):
                 ok = bench_cpu(args, ctx, sh, full, n, log_n, secret, out_xy, out_inf, result)
@@ -680,6 +685,47 @@ def bench_prove(ctx, sh, log_n, result) -> None:
         result["prove_native_valid"] = bool((pn["evals"][5] == zero_limbs).all())
     finally:
         chain.free()
+
+
+def bench_prove_2_22(dev_index, result) -> None:
+    """BASELINE config 5's size on this GPU, next to the 2^20 headline (review of round 4): the 2^22-row squaring chain,
+    quotient on the 2^24 coset, in the reference's proof shape through the one-call native prover and with batched
+    openings; its own context and SRS (tables c = 20), released before the CPU legs.  r(zeta) = 0 is checked here; the
+    proofs at this size are compared element for element with the single-rank / eight-rank / CPU provers by the test suite
+    (tests/test_gpu_prove.py, tests/test_gpu_dist.py) and by `bench.py --log-n 22`."""
+    from typlonk_amd.circuits import SquaringChain
+
+    log_n = 22
+    c2 = typlonk_amd.Context(dev_index)
+    try:
+        sid = c2.srs_generate(fr_mont_limbs(2), (1 << log_n) + 3)
+        c2.srs_precompute(sid, 20)
+        chain = SquaringChain(c2, log_n)
+        ch = [fr_mont_limbs(0x1234567 + k) for k in range(4)]
+        zero = np.zeros(4, dtype=np.uint64)
+        out = {"log_n": log_n}
+        pn = c2.prove_native(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            pn = c2.prove_native(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+        torch.cuda.synchronize()
+        out["prove_native_ms"] = (time.perf_counter() - t1) / 2 * 1e3
+        out["valid"] = bool((pn["evals"][5] == zero).all())
+        run_b = lambda: c2.prove(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets,   # noqa: E731
+                                 lambda c: (ch[0], ch[1]), lambda c: (ch[2], ch[3]), challenge_v=lambda e: ch[1])
+        run_b()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            run_b()
+        torch.cuda.synchronize()
+        out["prove_batched_openings_ms"] = (time.perf_counter() - t1) / 2 * 1e3
+        out["config"] = f"squaring chain, {chain.gates} gates, n = 2^{log_n}, quotient on the 2^{log_n + 2} coset"
+        result["prove_2_22"] = out
+        chain.free()
+    finally:
+        c2.close()
 
 
 def bench_cpu(args, ctx, sh, full, n, log_n, secret, out_xy, out_inf, result) -> bool:
