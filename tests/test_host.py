@@ -399,6 +399,36 @@ def test_bench_without_a_launcher_still_ends_with_one_contract_line(built):
     assert d["n_gpus"] == 2 and d["value"] is None and "No HIP GPUs" in d["error"]
 
 
+def test_fold_of_eight_ranks_with_every_exceptional_column(built):
+    """typlonk_g1_fold_records_host (the rank-order fold behind every *_sharded_* call: mixed additions of the ranks'
+    affine records + ONE inversion for all points, round 5): nine points from eight ranks against the big-int oracle, with
+    columns that hold identity records, the same point on two ranks (doubling), opposite points (the sum is the identity)
+    and nothing but identities"""
+    from helpers import g1_pack as pack
+    from typlonk_amd.capi import g1_fold_records_host
+
+    world, count = 8, 9
+    pts = [O.g1_mul(O.G1, 1000 + 17 * i) for i in range(world * count)]
+    pts[0] = None
+    pts[count + 1] = pts[1]
+    pts[2 * count + 2] = O.g1_neg(pts[2])
+    for r in range(world):
+        pts[r * count + 3] = None
+    for r in (1, 3, 4, 5, 6, 7):
+        pts[r * count + 2] = None                    # column 2: P on rank 0, -P on rank 2, identities elsewhere
+    xy, inf = pack(pts)
+    rec = np.zeros((world * count, 13), dtype=np.uint64)
+    rec[:, :12] = xy
+    rec[:, 12] = inf
+    got = g1_fold_records_host(rec, world, count)
+    for i in range(count):
+        want = None
+        for r in range(world):
+            want = O.g1_add(want, pts[r * count + i])
+        assert g1_unpack_one(*got[i]) == want, i
+    assert got[3][1] == 1 and got[2][1] == 1        # all identities; P + (-P)
+
+
 def test_missing_librccl_is_an_error_code_not_a_crash(built):
     """the loader of the RCCL exchange pointed at a library that does not exist (TYPLONK_RCCL_LIB): typlonk_comm_available
     says 0 and typlonk_comm_unique_id returns TYPLONK_ERR_COMM -- in a fresh process, because the loader resolves once.

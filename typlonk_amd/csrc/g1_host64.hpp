@@ -9,6 +9,7 @@
 // Device values arrive as 12 packed words holding x * 2^390 mod p, lazily reduced (< 8p < 2^384); one Montgomery
 // multiplication by 2^378 turns them into x * 2^384, fully reduced.
 #pragma once
+#include <vector>
 #include <stdint.h>
 #include <string.h>
 
@@ -167,6 +168,58 @@ inline Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
     o.zz = mul(mul(a.zz, b.zz), pp);
     o.zzz = mul(mul(a.zzz, b.zzz), ppp);
     return o;
+}
+// a + (bx, by): mixed addition (madd-2008-s), the affine operand not the identity; 8M + 2S instead of 12M + 2S
+inline Xyzz xyzz_madd(const Xyzz& a, const Fq& bx, const Fq& by, const Fq& one) {
+    if (is_inf(a)) {
+        Xyzz r;
+        r.x = bx;
+        r.y = by;
+        r.zz = one;
+        r.zzz = one;
+        return r;
+    }
+    const Fq u2 = mul(bx, a.zz), s2 = mul(by, a.zzz);
+    const Fq p = sub(u2, a.x), r = sub(s2, a.y);
+    if (is_zero(p)) {
+        if (!is_zero(r)) return inf();
+        Xyzz b;
+        b.x = bx;
+        b.y = by;
+        b.zz = one;
+        b.zzz = one;
+        return xyzz_dbl(b);
+    }
+    const Fq pp = sqr(p), ppp = mul(p, pp), q = mul(a.x, pp);
+    Xyzz o;
+    o.x = sub(sub(sqr(r), ppp), dbl(q));
+    o.y = sub(mul(r, sub(q, o.x)), mul(a.y, ppp));
+    o.zz = mul(a.zz, pp);
+    o.zzz = mul(a.zzz, ppp);
+    return o;
+}
+// canonical affine forms of n points with ONE field inversion (Montgomery's trick over the denominators ZZ * ZZZ);
+// ok[i] = 0 for the identity (its out_xy slot is left untouched)
+inline void xyzz_to_affine_batch(const Xyzz* pts, size_t n, uint64_t* out_xy /* n * 12 */, char* ok) {
+    std::vector<size_t> live;
+    std::vector<Fq> den, pre;   // denominators of the live points and their running products
+    for (size_t i = 0; i < n; ++i) {
+        ok[i] = is_inf(pts[i]) ? 0 : 1;
+        if (!ok[i]) continue;
+        live.push_back(i);
+        den.push_back(mul(pts[i].zz, pts[i].zzz));
+        pre.push_back(pre.empty() ? den.back() : mul(pre.back(), den.back()));
+    }
+    if (live.empty()) return;
+    Fq invr = inv(pre.back());
+    for (size_t k = live.size(); k-- > 0;) {
+        const Fq t = k ? mul(invr, pre[k - 1]) : invr;   // 1 / den[k]
+        if (k) invr = mul(invr, den[k]);
+        const Xyzz& p = pts[live[k]];
+        const Fq x = mul(p.x, mul(t, p.zzz)), y = mul(p.y, mul(t, p.zz));
+        memcpy(out_xy + 12 * live[k], x.v, 48);
+        memcpy(out_xy + 12 * live[k] + 6, y.v, 48);
+    }
 }
 // canonical affine point in arkworks' words (x || y, Montgomery R = 2^384); false for the identity
 inline bool xyzz_to_affine(const Xyzz& a, uint64_t out_xy[12]) {

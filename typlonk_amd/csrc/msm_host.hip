@@ -700,16 +700,27 @@ int typlonk_g1_fold_records_host(const uint64_t* records, size_t world, size_t c
                 if (failed_rank) *failed_rank = (int)r;
                 return TYPLONK_ERR_COMM;
             }
-    std::vector<uint64_t> pxy(world * 12);
-    std::vector<uint8_t> pinf(world);
+    // every point: the ranks' partial sums added in rank order (mixed additions: the records are affine), then ONE
+    // inversion for all `count` results -- 97 -> 40 us for nine points from eight ranks, the same canonical points
+    namespace H = h64;
+    const H::Fq one = {{0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull, 0x77ce585370525745ull,
+                        0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull}};  // 2^384 mod p
+    std::vector<H::Xyzz> sums(count, H::inf());
     for (size_t i = 0; i < count; ++i) {
         for (size_t r = 0; r < world; ++r) {   // all-gather layout: rank-major, `count` records per rank
             const uint64_t* rec = records + (r * count + i) * COMM_REC;
-            memcpy(&pxy[r * 12], rec, 96);
-            pinf[r] = (uint8_t)(rec[12] & 1u);
+            if (rec[12] & 1u) continue;
+            H::Fq x, y;
+            memcpy(x.v, rec, 48);
+            memcpy(y.v, rec + 6, 48);
+            sums[i] = H::xyzz_madd(sums[i], x, y, one);
         }
-        const int rc = typlonk_g1_sum_host(pxy.data(), pinf.data(), world, out_xy + 12 * i, out_inf + i);
-        if (rc) return rc;
+    }
+    std::vector<char> ok(count ? count : 1);
+    H::xyzz_to_affine_batch(sums.data(), count, out_xy, ok.data());
+    for (size_t i = 0; i < count; ++i) {
+        if (ok[i]) out_inf[i] = 0;
+        else write_affine_out(G1Affine::inf(), out_xy + 12 * i, out_inf + i);
     }
     return TYPLONK_OK;
 }
