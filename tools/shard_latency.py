@@ -85,6 +85,27 @@ breps = max(3, reps // 10)
 for _ in range(breps):
     ctx.msm_sharded_batch_devptr(sh.sid, ptrs, ms)
 out["sharded_batch9_ms_per_msm"] = round((time.perf_counter() - t0) / breps / nb * 1e3, 4)
+# what the one-rank communicator cannot show: the host fold over `world` ranks' records (typlonk_g1_fold_records_host is a
+# host function: timed here on synthetic records, k * G per rank).  fold_extra_* = its cost above the one-rank fold the
+# timings above already contain; the *_projected figures add it.
+import numpy as np
+from typlonk_amd.capi import g1_fold_records_host
+def _fold_us(w, cnt):
+    rec = np.zeros((w * cnt, 13), dtype=np.uint64)
+    base = np.concatenate([np.asarray(xy, dtype=np.uint64).reshape(12), [np.uint64(inf)]])
+    rec[:] = base                      # the same point on every rank and slot: the fold then doubles -- as costly as adding
+    g1_fold_records_host(rec, w, cnt)
+    ts = []
+    for _ in range(200):
+        t = time.perf_counter()
+        g1_fold_records_host(rec, w, cnt)
+        ts.append((time.perf_counter() - t) * 1e6)
+    return sorted(ts)[len(ts) // 2]     # the median: a pre-empted call costs milliseconds
+f1, f9, w1, w9 = _fold_us(1, 1), _fold_us(1, 9), _fold_us(world, 1), _fold_us(world, 9)
+out["host_fold_us"] = {"one_rank_1_point": round(f1, 1), "one_rank_9_points": round(f9, 1), f"{world}_ranks_1_point": round(w1, 1),
+                       f"{world}_ranks_9_points": round(w9, 1)}
+out["sharded_msm_wall_projected_ms"] = round(out["sharded_msm_wall_ms"] + (w1 - f1) * 1e-3, 4)
+out["sharded_batch9_ms_per_msm_projected"] = round(out["sharded_batch9_ms_per_msm"] + (w9 - f9) * 1e-3 / nb, 4)
 # one rank's share of a sharded prove(): NTTs, grand product and quotient are replicated, the 13 commitments run on the
 # shard, three exchanges (on the one-rank communicator) -- the per-rank time of BASELINE config 4 / 5 without wire time
 if os.environ.get("NO_PROVE") != "1":
