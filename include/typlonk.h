@@ -83,7 +83,7 @@ int typlonk_srs_download(typlonk_ctx* ctx, uint32_t srs_id, size_t offset, size_
  * terms would be slower than the plain path).  Later MSMs of at least len/4
  * terms over this SRS then let all windows share ONE bucket set: no cross-window doublings on the
  * host, fewer windows, fewer bucket additions.  Results are unchanged bit for bit.  Setup-time cost: T*c Jacobian doublings + ONE shared inversion per point
- * (T * len * 48 bytes of scratch during the call; without it one inversion per table entry).
+ * (plus T * len * 48 bytes of scratch for the duration of the call; TYPLONK_ERR_OOM if either allocation is refused).
  * An MSM length the table-mode sort cannot handle (more than 2^22 terms with 20-bit windows) silently takes the
  * plain path over the same SRS: precomputation never turns a valid MSM into an error. */
 #define TYPLONK_TABLES_AUTO_MIN_LEN 16384

@@ -100,7 +100,7 @@ TY_HD uint32_t msm_windows(uint32_t c, bool centred) {
     const uint32_t w0 = (bits + c - 1) / c;
     return w0 + ((bits - c * (w0 - 1)) == c ? 1u : 0u);
 }
-// zbuf: srs_tables_scratch_bytes(len, T) bytes of scratch (0 bytes / null: every entry is normalised by itself)
+// zbuf: srs_tables_scratch_bytes(len, T) bytes of scratch (one denominator per table entry)
 size_t srs_tables_scratch_bytes(uint64_t len, uint32_t T);
 void launch_srs_tables(uint32_t* pts, uint32_t* zbuf, uint64_t len, uint32_t c, uint32_t T, hipStream_t s);
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,

@@ -582,15 +582,9 @@ int typlonk_srs_precompute(typlonk_ctx* ctx, uint32_t srs_id, uint32_t window_bi
     DevGuard guard;
     guard.add(big);
     HIPCHK(hipMemcpyAsync(big, e.d_points, e.len * PT_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    // scratch of the shared normalisation (one denominator per entry); without it -- allocation refused -- every entry is
-    // normalised by itself, as in rounds 1-4
+    // scratch of the shared normalisation: one denominator per table entry, freed when the call returns
     uint32_t* zbuf = nullptr;
-    if (const size_t zb = srs_tables_scratch_bytes(e.len, T)) {
-        if (hipMalloc((void**)&zbuf, zb) != hipSuccess) {
-            (void)hipGetLastError();
-            zbuf = nullptr;
-        }
-    }
+    HIPCHK(hipMalloc((void**)&zbuf, srs_tables_scratch_bytes(e.len, T)));
     DevGuard zguard;
     zguard.add(zbuf);
     launch_srs_tables(big, zbuf, (uint64_t)e.len, window_bits, T, ctx->stream);

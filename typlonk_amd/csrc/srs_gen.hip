@@ -138,99 +138,13 @@ __global__ __launch_bounds__(64) void srs_tables_kernel(uint32_t* pts, uint32_t*
         st_fq(dst + 12, r.y);
     }
 }
-// rounds 1-4: every entry normalised by itself (kept for T too large for the LDS walk, and as the A/B reference)
-__global__ __launch_bounds__(64) void srs_tables_each_kernel(uint32_t* pts, uint64_t len, uint32_t c, uint32_t T) {
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    const uint64_t ii = i < len ? i : len - 1;
-    G1Affine p = ld_affine(pts, ii);
-    for (uint32_t t = 1; t < T; ++t) {
-        uint32_t* dst = pts + (t * len + ii) * PT_WORDS;
-        G1Xyzz acc = G1Xyzz::from_affine(p);
-        for (uint32_t d = 0; d < c; ++d) acc = g1_dbl(acc);
-        p = g1_to_affine(acc);
-        if (i < len) {
-            st_fq(dst, p.x);
-            st_fq(dst + 12, p.y);
-        }
-    }
-}
-size_t srs_tables_scratch_bytes(uint64_t len, uint32_t T) {
-    const size_t lds = (size_t)(T - 1) * 13 * 64 * 4;
-    return (T > 1 && lds <= 64 * 1024) ? (size_t)(T - 1) * len * 48 : 0;
-}
+// scratch of the walk: one denominator (48 B) per entry of tables 1 .. T-1.  The LDS holds (T - 1) x 13 words per thread:
+// 59.9 KiB for the largest table count the ABI accepts (c = 14: 19 tables), inside the 64 KiB a launch gets by default.
+size_t srs_tables_scratch_bytes(uint64_t len, uint32_t T) { return T > 1 ? (size_t)(T - 1) * len * 48 : 0; }
+static_assert((19 - 1) * 13 * 64 * 4 <= 64 * 1024, "the running products of the largest table count must fit the default LDS");
 void launch_srs_tables(uint32_t* pts, uint32_t* zbuf, uint64_t len, uint32_t c, uint32_t T, hipStream_t s) {
     if (T <= 1 || len == 0) return;
-    const dim3 grid((unsigned)((len + 63) / 64)), block(64);
-    if (zbuf && srs_tables_scratch_bytes(len, T)) {
-        hipLaunchKernelGGL(srs_tables_kernel, grid, block, (size_t)(T - 1) * 13 * 64 * 4, s, pts, zbuf, len, c, T);
-    } else {
-        hipLaunchKernelGGL(srs_tables_each_kernel, grid, block, 0, s, pts, len, c, T);
-    }
-}
-
-// ---- self-test of the SIMT inversion (typlonk_selftest_fq_inv) --------------------------------------------------------------
-// Every thread draws `per_thread` residues (xorshift; every 16th slot an edge value: 0, 1, 2, p - 1, p - 2, a one-limb
-// value), lifts them by 0..7 multiples of p (the contract of fq30_inv: any normalised value < 8p), and compares
-// fq30_inv_divsteps with the Fermat ladder a^(p-2) digit for digit after canonicalisation, plus x * x^-1 = 1.
-// out[0] = mismatches, out[1] = largest number of 30-divstep rounds a call ran, out[2] = calls.
-__global__ __launch_bounds__(64) void fq_inv_selftest_kernel(uint64_t seed, uint32_t per_thread, uint32_t* out) {
-    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
-    uint64_t st = (seed + tid) * 0x9E3779B97F4A7C15ull + 1;
-    uint32_t bad = 0;
-    int maxr = 0;
-    for (uint32_t it = 0; it < per_thread; ++it) {
-        Fq30 x;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            st ^= st << 13;
-            st ^= st >> 7;
-            st ^= st << 17;
-            x.v[i] = (uint32_t)st & FQ30_MASK;
-        }
-        x.v[12] &= 0x000fffffu;   // < 2^380 < p
-        const uint32_t cls = (it * 64u + threadIdx.x) & 255u;
-        if (cls < 6) {
-            const Fq30 keep = x;
-            x = fq30_zero();
-            if (cls == 1) x.v[0] = 1;
-            if (cls == 2) x.v[0] = 2;
-            if (cls == 3 || cls == 4) {
-#pragma unroll
-                for (int i = 0; i < 13; ++i) x.v[i] = fq30_kp(1, i);
-                x.v[0] -= cls == 3 ? 1u : 2u;
-            }
-            if (cls == 5) x.v[0] = keep.v[0];
-        }
-        Fq30 xl = x;
-        const uint32_t lift = (uint32_t)(st >> 40) & 7u;
-        for (uint32_t l = 0; l < lift; ++l) {
-            Fq30 pp;
-#pragma unroll
-            for (int i = 0; i < 13; ++i) pp.v[i] = fq30_kp(1, i);
-            xl = fq30_add_lazy(xl, pp);
-        }
-        int rounds = 0;
-        const Fq30 d = fq30_canon(fq30_inv_divsteps(xl, &rounds));
-        const Fq30 f = fq30_canon(fq30_inv_fermat(x));
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) ok = ok && d.v[i] == f.v[i];
-        if (!fq30_is_zero_exact(x)) {
-            const Fq30 one = fq30_canon(fq30_mul(xl, d)), r1 = fq30_one();
-#pragma unroll
-            for (int i = 0; i < 13; ++i) ok = ok && one.v[i] == r1.v[i];
-        } else {
-            ok = ok && fq30_is_zero_exact(d);
-        }
-        bad += ok ? 0u : 1u;
-        maxr = rounds > maxr ? rounds : maxr;
-    }
-    if (bad) atomicAdd(&out[0], bad);
-    atomicMax(&out[1], (uint32_t)maxr);
-    atomicAdd(&out[2], per_thread);
-}
-void launch_fq_inv_selftest(uint64_t seed, uint32_t threads, uint32_t per_thread, uint32_t* out, hipStream_t st) {
-    hipLaunchKernelGGL(fq_inv_selftest_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, seed, per_thread, out);
+    hipLaunchKernelGGL(srs_tables_kernel, dim3((unsigned)((len + 63) / 64)), dim3(64), (size_t)(T - 1) * 13 * 64 * 4, s, pts, zbuf, len, c, T);
 }
 
 void launch_srs_comb(uint32_t* comb, hipStream_t st) {
