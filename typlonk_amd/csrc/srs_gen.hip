@@ -147,6 +147,71 @@ void launch_srs_tables(uint32_t* pts, uint32_t* zbuf, uint64_t len, uint32_t c, 
     hipLaunchKernelGGL(srs_tables_kernel, dim3((unsigned)((len + 63) / 64)), dim3(64), (size_t)(T - 1) * 13 * 64 * 4, s, pts, zbuf, len, c, T);
 }
 
+// ---- self-test of the SIMT inversion (typlonk_selftest_fq_inv) --------------------------------------------------------------
+// Every thread draws `per_thread` residues (xorshift; every 16th slot an edge value: 0, 1, 2, p - 1, p - 2, a one-limb
+// value), lifts them by 0..7 multiples of p (the contract of fq30_inv: any normalised value < 8p), and compares
+// fq30_inv_divsteps with the Fermat ladder a^(p-2) digit for digit after canonicalisation, plus x * x^-1 = 1.
+// out[0] = mismatches, out[1] = largest number of 30-divstep rounds a call ran, out[2] = calls.
+__global__ __launch_bounds__(64) void fq_inv_selftest_kernel(uint64_t seed, uint32_t per_thread, uint32_t* out) {
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+    uint64_t st = (seed + tid) * 0x9E3779B97F4A7C15ull + 1;
+    uint32_t bad = 0;
+    int maxr = 0;
+    for (uint32_t it = 0; it < per_thread; ++it) {
+        Fq30 x;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            st ^= st << 13;
+            st ^= st >> 7;
+            st ^= st << 17;
+            x.v[i] = (uint32_t)st & FQ30_MASK;
+        }
+        x.v[12] &= 0x000fffffu;   // < 2^380 < p
+        const uint32_t cls = (it * 64u + threadIdx.x) & 255u;
+        if (cls < 6) {
+            const Fq30 keep = x;
+            x = fq30_zero();
+            if (cls == 1) x.v[0] = 1;
+            if (cls == 2) x.v[0] = 2;
+            if (cls == 3 || cls == 4) {
+#pragma unroll
+                for (int i = 0; i < 13; ++i) x.v[i] = fq30_kp(1, i);
+                x.v[0] -= cls == 3 ? 1u : 2u;
+            }
+            if (cls == 5) x.v[0] = keep.v[0];
+        }
+        Fq30 xl = x;
+        const uint32_t lift = (uint32_t)(st >> 40) & 7u;
+        for (uint32_t l = 0; l < lift; ++l) {
+            Fq30 pp;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) pp.v[i] = fq30_kp(1, i);
+            xl = fq30_add_lazy(xl, pp);
+        }
+        int rounds = 0;
+        const Fq30 d = fq30_canon(fq30_inv_divsteps(xl, &rounds));
+        const Fq30 f = fq30_canon(fq30_inv_fermat(x));
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) ok = ok && d.v[i] == f.v[i];
+        if (!fq30_is_zero_exact(x)) {
+            const Fq30 one = fq30_canon(fq30_mul(xl, d)), r1 = fq30_one();
+#pragma unroll
+            for (int i = 0; i < 13; ++i) ok = ok && one.v[i] == r1.v[i];
+        } else {
+            ok = ok && fq30_is_zero_exact(d);
+        }
+        bad += ok ? 0u : 1u;
+        maxr = rounds > maxr ? rounds : maxr;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicMax(&out[1], (uint32_t)maxr);
+    atomicAdd(&out[2], per_thread);
+}
+void launch_fq_inv_selftest(uint64_t seed, uint32_t threads, uint32_t per_thread, uint32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(fq_inv_selftest_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, seed, per_thread, out);
+}
+
 void launch_srs_comb(uint32_t* comb, hipStream_t st) {
     hipLaunchKernelGGL(srs_comb_kernel, dim3(COMB_WINDOWS * COMB_ROW / 64), dim3(64), 0, st, comb);
 }
