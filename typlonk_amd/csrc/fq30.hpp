@@ -563,7 +563,7 @@ inline Fq30 fq30_inv_gcd(const Fq30& a) {
 // d * a = f and e * a = g (mod p).  At g = 0: f = +-gcd = +-1 and a^-1 = +-d; a = 0 leaves d = 0 (0 -> 0).
 // Integers are 13 signed limbs: limbs 0..11 in [0, 2^30), limb 12 carries the sign.
 // A lane never leaves the loop alone: the exit test is wave-uniform (all lanes at g = 0; once there, further rounds
-// change neither f nor d), so the usual count is the slowest lane's ~25 rounds, the bound 37 (-DFQ30_INV_FIXED_ROUNDS:
+// change neither f nor d), so the usual count is the slowest lane's 26-28 rounds, the bound 37 (-DFQ30_INV_FIXED_ROUNDS:
 // always 37, for a data-independent instruction stream).
 constexpr int FQ30_DIVSTEP_ROUNDS = 37;
 constexpr uint32_t FQ30_PINV = 0x00030003u;   // p^-1 mod 2^30
