@@ -201,17 +201,21 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
                 launch_msm_scatter(keys, (uint64_t)mk, total, cursor, sorted, ss);
             }
         }
-        {
-            StageTimer st(ctx, "msm_order", ss);
-            launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.order.p,
-                                (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, /*hist_done=*/segsort, ss);
-        }
-        if (ss != s) {
+        // The bucket schedule of an overlapped chunk is built on the MSM's own stream, behind the previous accumulation:
+        // the overlapped sort ends about when that accumulation does (it only gets the slots the accumulation leaves),
+        // so on the side stream the schedule kernel was one more cross-stream hand-over on the critical path
+        // (same-box A/B, profiles/r05_ab_order_on_main.txt: 2.632 -> 2.592 ms per stand-alone 2^20 MSM, 2^22 unchanged)
+        const bool order_main = ss != s;
+        if (order_main) {
             HIPCHK(hipEventRecord(ws.ev_sorted[k], ss));
             HIPCHK(hipStreamWaitEvent(s, ws.ev_sorted[k], 0));
-        } else if (nch > 1 && k == 0) {
-            HIPCHK(hipEventRecord(ws.ev_sorted[0], s));
         }
+        {
+            StageTimer st(ctx, "msm_order", s);
+            launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.order.p,
+                                (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, /*hist_done=*/segsort, s);
+        }
+        if (!order_main && nch > 1 && k == 0) HIPCHK(hipEventRecord(ws.ev_sorted[0], s));
         {
             // lanes per bucket: a short MSM over a small bucket set has few, long buckets -- spread each over L lanes so
             // that the launch fills the chip twice over (>= 2^18 threads: two rounds of two wavefronts per SIMD balance the
