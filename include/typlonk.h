@@ -58,7 +58,7 @@ const char* typlonk_last_error(const typlonk_ctx* ctx); /* detail text of the la
  * NULL restores the context's own stream.
  *
  * STREAM ORDERING of device-resident inputs.  Every entry point that reads caller-owned device memory
- * (typlonk_msm_g1_devptr, typlonk_msm_g1_batch_devptr, typlonk_ntt_fr_devptr, and the typlonk_buf forms when the
+ * (typlonk_msm_g1_devptr, typlonk_msm_g1_batch_devptr, typlonk_ntt_fr_devptr, typlonk_ntt_fr_batch_devptr, and the typlonk_buf forms when the
  * buffer was written through typlonk_buf_devptr) reads it in the order of the CONTEXT'S STREAM.  The context's own
  * stream is an ordinary (blocking) HIP stream, so it is also ordered after everything previously submitted to the
  * legacy default stream -- which is where PyTorch-ROCm runs unless told otherwise.  A producer on any OTHER stream
@@ -176,6 +176,15 @@ int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32
                        const uint64_t* coset_shift);
 int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int inverse,
                           const uint64_t* coset_shift);
+/* `count` transforms of the same size, direction and coset in one call: d_data[v] is a device pointer to 2^log_n Fr
+ * elements, transformed in place; the vectors must not overlap (TYPLONK_ERR_INVALID_ARG).  The reference always
+ * transforms in groups -- `interpolate` of the three wire columns (plonk/src/proof.rs:50), their re-evaluation
+ * (:113-115), the three sigma columns (:334-338, :412-418), the five selector columns (plonk/src/builder.rs:84-88) --
+ * so every pass of the group is ONE launch carrying count x the tiles of a single vector over shared twiddle tables
+ * (as typlonk_msm_g1_batch_devptr does for the group's commitments).  Bit-identical to `count` single calls;
+ * count = 0 is a no-op; stream-ordered like the _devptr form. */
+int typlonk_ntt_fr_batch_devptr(typlonk_ctx* ctx, void* const* d_data, size_t count, uint32_t log_n, int inverse,
+                                const uint64_t* coset_shift);
 
 /* ---- quotient polynomial (plonk::proof::quotient_polynomial, /root/reference/plonk/src/proof.rs:292-375)
  * All inputs are device-resident coefficient vectors of n = 2^log_n elements (zero padded), as

@@ -4,6 +4,7 @@
 // All Fq / G1 arguments are in the C-ABI (arkworks) form: 12 u32 words per coordinate, R = 2^384.
 #include "../../typlonk_amd/csrc/g1.hpp"
 #include "../../typlonk_amd/csrc/g1_host64.hpp"
+#include "../../typlonk_amd/csrc/fr_inv.hpp"
 #include "../../typlonk_amd/csrc/transcript.hpp"
 #include <string.h>
 using namespace ty;
@@ -26,6 +27,12 @@ void shim_fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_m
 void shim_fr_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_add(ld<Fr>(a), ld<Fr>(b))); }
 void shim_fr_sub(const uint32_t* a, const uint32_t* b, uint32_t* o) { st(o, fe_sub(ld<Fr>(a), ld<Fr>(b))); }
 void shim_fr_inv(const uint32_t* a, uint32_t* o) { st(o, fe_inv(ld<Fr>(a))); }
+// the device's divsteps inversion of Fr (fr_inv.hpp), compiled for the host; returns the number of 30-step rounds it ran
+int shim_fr_inv_divsteps(const uint32_t* a, uint32_t* o) {
+    int rounds = 0;
+    st(o, fr_inv_divsteps(ld<Fr>(a), &rounds));
+    return rounds;
+}
 void shim_fr_from_mont(const uint32_t* a, uint32_t* o) { st(o, fe_from_mont(ld<Fr>(a))); }
 void shim_fr_to_mont(const uint32_t* a, uint32_t* o) { st(o, fe_to_mont(ld<Fr>(a))); }
 

@@ -209,7 +209,12 @@ def _native_ranks(world, log_n, tmp_path, tables=False, timeout=900):
         env = dict(os.environ, TYPLONK_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_S="300", TABLES="1" if tables else "0")
         env.pop("TYPLONK_TEST_COMM_FAIL_STAGING", None)
         if r == world - 1:
-            env["TYPLONK_TEST_COMM_FAIL_STAGING"] = "1"      # this rank's FIRST fold loses its staging copy
+            # this rank's FIRST fold loses its staging copy: the fault injection exists only in the test build of the
+            # library (-DTYPLONK_TEST_HOOKS); every other rank runs the shipped one
+            hooked = os.path.join(ROOT, "tests", "cpp", "hooks", "libtyplonk_hip.so")
+            assert os.path.exists(hooked), "tests/cpp/hooks/libtyplonk_hip.so not built (__graft_entry__.build())"
+            env["TYPLONK_LIB_PATH"] = hooked
+            env["TYPLONK_TEST_COMM_FAIL_STAGING"] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_native_worker.py"), str(r), str(world),
                                        str(tmp_path), str(log_n)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True, cwd=ROOT))

@@ -170,6 +170,77 @@ def test_both_butterfly_kernels_give_the_c_oracles_words(built, mode, monkeypatc
         c2.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_batched_transforms_equal_single_calls_in_every_kernel_mode(built, mode, monkeypatch):
+    """typlonk_ntt_fr_batch_devptr: `count` vectors of one size / direction / coset, every pass ONE launch carrying count x
+    the tiles of a vector.  The reference transforms in such groups (the three wire columns plonk/src/proof.rs:50, their
+    re-evaluation :113-115, the three sigmas :334-338, the five selectors plonk/src/builder.rs:84-88).  Must be bit-identical
+    to `count` single calls -- and to the C restatement of ark-poly's FFT -- in all three TYPLONK_NTT_FR30 modes, for
+    count = 1, 3, 5, 8 and 11 (11 = two launch groups), forward, inverse, coset and inverse coset, one to three passes and
+    the two-pass 2^20 plan; count = 0 is a no-op; overlapping vectors and a null entry are refused."""
+    import typlonk_amd
+    from oracle import coracle as CO
+    from typlonk_amd.capi import ERR_INVALID_ARG, TyplonkError
+
+    monkeypatch.setenv("TYPLONK_NTT_FR30", str(mode))
+    c2 = typlonk_amd.Context(0)
+    try:
+        g = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
+        c2.ntt_batch_devptr([], 10)                                   # count = 0
+        for log_n, counts in ((0, (3,)), (1, (3,)), (6, (5,)), (10, (1, 8)), (13, (3, 11)), (17, (3,)), (20, (3, 5))):
+            n = 1 << log_n
+            for count in counts:
+                buf = c2.alloc(n * count)
+                x = rand_limbs(9100 + 17 * log_n + count + mode, n * count)
+                x[0] = 0
+                x[-1] = np.array(O.fr_to_mont_limbs(O.R - 1), dtype=np.uint64)
+                ptrs = [buf.devptr + 32 * n * v for v in range(count)]
+                for inverse, coset in ((False, None), (True, None), (False, g), (True, g)):
+                    if log_n == 20 and coset is not None and inverse:
+                        continue                                        # (keeps the test inside a few seconds of CPU oracle)
+                    buf.upload(x)
+                    c2.ntt_batch_devptr(ptrs, log_n, inverse=inverse, coset=coset)
+                    got = buf.download()
+                    for v in range(count):
+                        xv = x[v * n:(v + 1) * n]
+                        single = c2.ntt(xv, log_n, inverse=inverse, coset=coset)
+                        assert (got[v * n:(v + 1) * n] == single).all(), (mode, log_n, count, v, inverse, coset is not None)
+                        if v == 0 or log_n <= 13:
+                            assert (single == CO.ntt(xv, log_n, inverse=inverse, coset=coset)).all()
+        buf = c2.alloc(3 << 10)
+        with pytest.raises(TyplonkError) as e:
+            c2.ntt_batch_devptr([buf.devptr, buf.devptr + 32 * 512], 10)   # the second vector starts inside the first
+        assert e.value.code == ERR_INVALID_ARG
+        with pytest.raises(TyplonkError) as e:
+            c2.ntt_batch_devptr([buf.devptr, 0], 10)
+        assert e.value.code == ERR_INVALID_ARG
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("big", [0, 2])
+def test_batched_2_20_both_plans(built, big, monkeypatch):
+    """the 2^20 batch in both pass plans (TYPLONK_NTT_BIG = 0: three passes on 1024-element tiles, 2: the two-pass plan on
+    4096-element tiles): same words as the C oracle, all three vectors"""
+    import typlonk_amd
+    from oracle import coracle as CO
+
+    monkeypatch.setenv("TYPLONK_NTT_BIG", str(big))
+    c2 = typlonk_amd.Context(0)
+    try:
+        n, count = 1 << 20, 3
+        x = rand_limbs(9900 + big, n * count)
+        buf = c2.alloc(n * count)
+        for inverse in (False, True):
+            buf.upload(x)
+            c2.ntt_batch_devptr([buf.devptr + 32 * n * v for v in range(count)], 20, inverse=inverse)
+            got = buf.download()
+            for v in range(count):
+                assert (got[v * n:(v + 1) * n] == CO.ntt(x[v * n:(v + 1) * n], 20, inverse=inverse)).all(), (big, inverse, v)
+    finally:
+        c2.close()
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("log_n", [26, 27])
 def test_beyond_the_full_table_limit_vs_c_oracle(ctx, log_n):

@@ -46,6 +46,27 @@ def test_fr_arithmetic_vs_bigint(shim):
         assert O.fr_from_mont_limbs(_call(shim, "shim_fr_inv", 4, _fr(a))) == pow(a, -1, O.R)
 
 
+def test_fr_divsteps_inversion_vs_bigint(shim):
+    """the device's Fr inversion (csrc/fr_inv.hpp: Bernstein-Yang divsteps on nine signed 30-bit limbs; the grand product's
+    one inversion, permutation/src/proving.rs:18-24) compiled for the host: equal to Python's pow and to the Fermat ladder
+    on edge values and 3000 random residues, 0 -> 0, inside the 25-round bound of Theorem 11.2"""
+    rnd = random.Random(11)
+    edge = [0, 1, 2, 3, O.R - 1, O.R - 2, (O.R + 1) // 2, (1 << 254) % O.R, (1 << 30) - 1, 1 << 30, (1 << 240) + 1,
+            pow(1 << 256, -1, O.R), (1 << 256) % O.R]
+    worst = 0
+    for it in range(3000):
+        a = edge[it] if it < len(edge) else rnd.randrange(O.R)
+        o = np.zeros(4, dtype=np.uint64)
+        rounds = shim.shim_fr_inv_divsteps(u32p(_fr(a)), u32p(o))
+        got = O.fr_from_mont_limbs([int(v) for v in o])
+        assert got == (pow(a, -1, O.R) if a else 0), hex(a)
+        assert 0 <= rounds <= 25
+        worst = max(worst, rounds)
+        if it < 40:
+            assert [int(v) for v in o] == _call(shim, "shim_fr_inv", 4, _fr(a))   # same words as a^(r-2)
+    assert worst >= 15   # the loop really runs (a broken early exit would return the initial d = 0)
+
+
 def _q(shim, fn, *args):
     """call a shim Fq function: numpy arrays are passed as u32 pointers, ints as ints"""
     o = np.zeros(6, dtype=np.uint64)
@@ -266,6 +287,15 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
                     src = open(os.path.join(dirpath, f)).read()
                     assert not pat.search(src), f"{f} references the oracle"
+
+
+def test_shipped_library_has_no_test_hooks(built):
+    """fault injection lives in the test build only (tests/cpp/hooks, -DTYPLONK_TEST_HOOKS): the shipped library must not
+    read any TYPLONK_TEST_* switch from the environment; the hooked build must"""
+    shipped = open(os.path.join(ROOT, "typlonk_amd", "libtyplonk_hip.so"), "rb").read()
+    assert b"TYPLONK_TEST" not in shipped
+    hooked = open(os.path.join(ROOT, "tests", "cpp", "hooks", "libtyplonk_hip.so"), "rb").read()
+    assert b"TYPLONK_TEST_COMM_FAIL_STAGING" in hooked
 
 
 # ---- Fiat-Shamir transcript (tests/transcript_ref.py, the harness's separate Python statement; unverifiable against Rust here, see its docstring) -------

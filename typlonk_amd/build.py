@@ -1,6 +1,7 @@
 """Build recipe for the in-tree native artefacts (gfx950 only).
 
   typlonk_amd/libtyplonk_hip.so   HIP kernels + C ABI (include/typlonk.h)       -- hipcc
+  tests/cpp/hooks/libtyplonk_hip.so  the same library with the fault-injection hook (-DTYPLONK_TEST_HOOKS, tests only) -- hipcc
   tests/cpp/libff_host_shim.so    host shim over the shared arithmetic headers  -- g++
   tests/cpp/test_{poly,kzg,plonk}_host  tests of the C++ host mirror (typlonk_amd/host) -- g++
 
@@ -93,11 +94,32 @@ def build_hip_variant(name: str, unit_flags: dict[str, list[str]]) -> str:
     return lib
 
 
+def build_hip_test_hooks(force: bool = False) -> str:
+    """tests/cpp/hooks/libtyplonk_hip.so: the library with comm.hip compiled under -DTYPLONK_TEST_HOOKS (the staging-failure
+    injection of tests/test_gpu_dist.py).  Test-only: the shipped library carries no such switch; the dist tests load this
+    build through TYPLONK_LIB_PATH in the rank that is meant to fail."""
+    out_dir = os.path.join(ROOT, "tests", "cpp", "hooks")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libtyplonk_hip.so")
+    hipcc = hipcc_path()
+    build_hip()
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "typlonk.h")]
+    src = os.path.join(CSRC, "comm.hip")
+    obj = os.path.join(out_dir, "comm.o")
+    base_obj = os.path.join(CSRC, "_obj")
+    objs = [obj if u == "comm.hip" else os.path.join(base_obj, u.replace(".hip", ".o")) for u in HIP_UNITS]
+    if force or _stale(obj, [src] + hdrs):
+        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DTYPLONK_TEST_HOOKS", "-c", src, "-o", obj])
+    if force or _stale(lib, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
+
+
 def build_host_shim(force: bool = False) -> str:
     src = os.path.join(ROOT, "tests", "cpp", "ff_host_shim.cpp")
     out = os.path.join(ROOT, "tests", "cpp", "libff_host_shim.so")
     deps = [src, os.path.join(CSRC, "ff.hpp"), os.path.join(CSRC, "g1.hpp"), os.path.join(CSRC, "fq30.hpp"), os.path.join(CSRC, "g1_host64.hpp"),
-            os.path.join(CSRC, "transcript.hpp")]
+            os.path.join(CSRC, "fr30.hpp"), os.path.join(CSRC, "fr_inv.hpp"), os.path.join(CSRC, "transcript.hpp")]
     if force or _stale(out, deps):
         _run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", out])
     return out
@@ -133,6 +155,7 @@ def build_fake_rccl(force: bool = False) -> str:
 
 def build_all(force: bool = False) -> None:
     build_hip(force)
+    build_hip_test_hooks(force)
     build_host_shim(force)
     build_host_tests(force)
     build_fake_rccl(force)

@@ -22,7 +22,7 @@ SYMBOLS = [
     "typlonk_init", "typlonk_destroy", "typlonk_strerror", "typlonk_last_error", "typlonk_set_stream",
     "typlonk_sync", "typlonk_srs_load", "typlonk_srs_generate", "typlonk_srs_download", "typlonk_srs_precompute", "typlonk_srs_set_shard", "typlonk_srs_free", "typlonk_srs_len", "typlonk_msm_g1",
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
-    "typlonk_ntt_fr_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
+    "typlonk_ntt_fr_devptr", "typlonk_ntt_fr_batch_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
     "typlonk_prover_round3", "typlonk_prover_round3_evals", "typlonk_prover_round4_batched", "typlonk_prover_free",
     "typlonk_prove", "typlonk_transcript_challenges", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
@@ -125,6 +125,10 @@ def load_library() -> C.CDLL:
     lib.typlonk_ntt_fr.argtypes = [vp, u64p, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int, u64p]
     lib.typlonk_ntt_fr_devptr.argtypes = [vp, vp, C.c_uint32, C.c_int, u64p]
+    # (an A/B build of an OLDER revision, loaded through TYPLONK_LIB_PATH for a same-box measurement, may predate this
+    # entry point; the in-tree library must export it -- tests/test_host.py checks every symbol of the header)
+    if hasattr(lib, "typlonk_ntt_fr_batch_devptr") or not os.environ.get("TYPLONK_LIB_PATH"):
+        lib.typlonk_ntt_fr_batch_devptr.argtypes = [vp, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint32, C.c_int, u64p]
     lib.typlonk_quotient_dev.argtypes = [vp, C.POINTER(QuotientArgs), C.c_uint32, vp]
     lib.typlonk_grand_product_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, u64p, C.POINTER((C.c_uint64 * 4) * 3),
                                               C.c_uint32, vp]
@@ -458,6 +462,12 @@ class Context:
     def ntt_devptr(self, devptr: int, log_n: int, inverse: bool = False, coset=None):
         keep, cp = self._coset(coset)
         self._chk(self.lib.typlonk_ntt_fr_devptr(self.h, devptr, log_n, int(inverse), cp))
+
+    def ntt_batch_devptr(self, devptrs, log_n: int, inverse: bool = False, coset=None):
+        """typlonk_ntt_fr_batch_devptr: len(devptrs) vectors of 2^log_n Fr, each transformed in place, every pass one launch"""
+        keep, cp = self._coset(coset)
+        ptrs = (C.c_void_p * max(len(devptrs), 1))(*[int(p) for p in devptrs])
+        self._chk(self.lib.typlonk_ntt_fr_batch_devptr(self.h, ptrs, len(devptrs), log_n, int(inverse), cp))
 
     def grand_product_dev(self, log_n: int, wire_evals, sigma_evals, beta, gamma, cosets, z_out):
         """typlonk_grand_product_dev: column / sigma EVALUATIONS (DeviceBuffers) -> Z evaluations"""

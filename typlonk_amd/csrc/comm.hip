@@ -10,6 +10,9 @@ using namespace tyh;
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <mutex>
+
 namespace {
 // RCCL entry points, resolved once per process.  The library is NOT linked: a single-GPU caller never loads it, and in
 // a process that already holds a copy (PyTorch's) dlopen by SONAME returns that copy, which is bound to the same HIP
@@ -23,9 +26,16 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
+void rccl_resolve(RcclApi& api);
+// first use from any thread resolves the entry points exactly once (a Rust caller keeps one Backend per thread, so two
+// threads may reach their first typlonk_comm_* call together)
 RcclApi* rccl_api() {
     static RcclApi api;
-    if (api.handle || !api.err.empty()) return &api;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_resolve(api); });
+    return &api;
+}
+void rccl_resolve(RcclApi& api) {
     // TYPLONK_RCCL_LIB names the library to load (a deployment with its own RCCL build); otherwise the SONAME, which a
     // process that already holds a copy resolves to that copy
     const char* forced = getenv("TYPLONK_RCCL_LIB");
@@ -39,7 +49,7 @@ RcclApi* rccl_api() {
     }
     if (!api.handle) {
         api.err = "cannot load librccl: " + why;
-        return &api;
+        return;
     }
     auto sym = [&](const char* n) -> void* {
         void* f = dlsym(api.handle, n);
@@ -51,7 +61,6 @@ RcclApi* rccl_api() {
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
     api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
-    return &api;
 }
 }  // namespace
 
@@ -65,14 +74,20 @@ namespace tyh {
             return fail(ctx, TYPLONK_ERR_COMM, std::string(#expr) + ": " + rccl_api()->GetErrorString(_r));           \
     } while (0)
 
-// TYPLONK_TEST_COMM_FAIL_STAGING=<k>: the k-th fold of this process (1-based) behaves as if its staging copy had failed
-// -- the one local failure between "decided to fold" and the collective that cannot be provoked from outside
+// Fault injection for the one local failure between "decided to fold" and the collective that cannot be provoked from
+// outside: a lost staging copy.  Compiled ONLY into the test build of the library (-DTYPLONK_TEST_HOOKS,
+// typlonk_amd/build.py build_hip_test_hooks -> tests/cpp/hooks/libtyplonk_hip.so); the shipped library has no such switch.
+//   TYPLONK_TEST_COMM_FAIL_STAGING=<k>: the k-th fold of this process (1-based) behaves as if its staging copy had failed
 // (tests/test_gpu_dist.py: the peers must get TYPLONK_ERR_COMM, not a hang, and the next fold must work).
+#ifdef TYPLONK_TEST_HOOKS
 static bool comm_test_fail_staging() {
     static const int target = [] { const char* e = getenv("TYPLONK_TEST_COMM_FAIL_STAGING"); return e ? atoi(e) : 0; }();
-    static int calls = 0;
+    static std::atomic<int> calls{0};
     return target > 0 && ++calls == target;
 }
+#else
+static constexpr bool comm_test_fail_staging() { return false; }
+#endif
 
 void comm_release(typlonk_ctx* ctx) {
     Comm& c = ctx->comm;

@@ -123,6 +123,9 @@ struct typlonk_buf {
 //   TYPLONK_MSM_LANES     lanes per bucket of the accumulation (1, 2, 4, 8, 16; 0 = by bucket load)
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
 //   TYPLONK_NTT_FR30      0 | 1 | 2: the 9 x 30-bit butterflies never / where they measure faster / always
+//   TYPLONK_NTT_BIG       0 | 1 | 2: the two-pass 2^20 plan (4096-element tiles) never / where it measures faster / always
+//   TYPLONK_PROVER_NTT_BATCH 0 | 1: round 1 transforms its columns one by one (each commitment submitted as soon as its
+//                         polynomial exists) / as one batched transform per group (ntt_run_batch)
 //   TYPLONK_PROVER_PIPE   0 | 1: round 3's nine commitments queued as in rounds 1-4 / behind one fence (prover_round3_core)
 // (TYPLONK_RCCL_LIB, read by comm.hip, names the RCCL library to load.)
 struct typlonk_ctx {
@@ -135,6 +138,7 @@ struct typlonk_ctx {
     std::map<uint32_t, tyh::CircuitEntry> circuits;
     uint32_t next_circuit = 1;
     tyh::DevBuf srs_comb;          // fixed-base comb of G (typlonk_srs_generate, srs_gen.hip)
+    bool srs_comb_ready = false;   // set once the comb's build kernel has run to completion
     // MSM
     tyh::DevBuf scal;
     static constexpr int MSM_LANES = 4;
@@ -158,6 +162,7 @@ struct typlonk_ctx {
     // 0.419 -> 0.464 ms per MSM -- so the switch sits below the shard size; from 2^19 on the chain is never worse and
     // 2^20 needs it.  -1 = by term count (MSM_CHAIN_MIN_TERMS), 0 / 1 = TYPLONK_MSM_CHAIN.
     int msm_chain = -1;
+    bool prover_ntt_batch = true;  // TYPLONK_PROVER_NTT_BATCH: round 1's interpolations / coset extensions as batched transforms
     bool prover_pipe = true;       // TYPLONK_PROVER_PIPE (A/B switch of the round-5 queueing fix, prover_round3_core)
     int msm_chunks = 0;            // chunks of a stand-alone MSM (0 = choose by length)
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
@@ -175,6 +180,8 @@ struct typlonk_ctx {
     static constexpr size_t COSET_BYTES_MAX = (size_t)3 << 30;
     int ntt_fr30 = 1;              // 0 = the 8 x 32-bit kernel everywhere, 1 = the default policy (9 x 30-bit butterflies, fr30.hpp, for
                                    // every inverse transform and for forward ones up to 2^NTT_FR30_FWD_MAX_LOG), 2 = 30-bit everywhere
+    int ntt_big = 1;               // TYPLONK_NTT_BIG: the two-pass 2^20 plan on 4096-element tiles 0 = never, 1 = where it measures
+                                   // faster (ntt_run_batch), 2 = for every 2^20 transform outside a prover round
     // profiling
     bool profiling = false;
     std::vector<tyh::ProfStage> prof;
@@ -280,6 +287,10 @@ int get_pow2l(typlonk_ctx* ctx, const std::string& key, const Fr& base, const Fr
 // element beyond as zero (no padded copy, no reads of zeros or of their coset factors); the result lands in d_data.
 int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift, bool sync = true,
             const Fr* short_in = nullptr, uint64_t n_valid = ~0ull);
+// `count` transforms of one size / direction / coset, pass by pass in shared launches (d_data[v] in place; short_in: NULL or
+// one zero-padded source per vector, all n_valid long)
+int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t log_n, int inverse, const uint64_t* coset_shift,
+                  bool sync = true, const Fr* const* short_in = nullptr, uint64_t n_valid = ~0ull);
 
 // ---- msm_host.hip ---------------------------------------------------------------------------------------------------
 void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf);   // internal affine -> the C-ABI's arkworks form

@@ -57,7 +57,8 @@ struct GrandProductArgs {
 };
 void launch_gp_terms(const GrandProductArgs& a, hipStream_t s);
 void launch_product_scan(const Fr* in, uint64_t n, int reverse, Fr* block_scratch, Fr* out, hipStream_t s);
-void launch_gp_finish(const Fr* nprefix, const Fr* dsuffix, const Fr& inv_total, uint64_t n, Fr* z, hipStream_t s);
+void launch_fr_inv(const Fr* in, Fr* out, hipStream_t s);   // out[0] = in[0]^-1 on the device (one wavefront)
+void launch_gp_finish(const Fr* nprefix, const Fr* dsuffix, const Fr* inv_total /* device */, uint64_t n, Fr* z, hipStream_t s);
 
 // open(): y = p(z) and q = (p - y)/(X - z) in one suffix scan; m <= 2^22 coefficients, q may be null
 void launch_open(const Fr* c, uint64_t m, const Fr& z, Fr* q, Fr* blocks, Fr* y, hipStream_t s);

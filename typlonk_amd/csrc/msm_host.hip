@@ -518,7 +518,8 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
     if (len) {
         Fr s;
         memcpy(s.v, secret, sizeof(s.v));
-        if (!ctx->srs_comb.p) {   // [j 2^(8w)] G, once per context
+        const bool build_comb = !ctx->srs_comb_ready;   // [j 2^(8w)] G, once per context
+        if (build_comb) {
             const int rc = ensure(ctx, ctx->srs_comb, srs_comb_bytes());
             if (rc != TYPLONK_OK) return rc;
             launch_srs_comb((uint32_t*)ctx->srs_comb.p, ctx->stream);
@@ -527,6 +528,7 @@ int typlonk_srs_generate(typlonk_ctx* ctx, const uint64_t secret[4], uint64_t st
         launch_srs_generate(s, start, (uint64_t)len, (const uint32_t*)ctx->srs_comb.p, e.d_points, ctx->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->srs_comb_ready = true;   // only now: a failed build is repeated by the next call, never read
     }
     guard.dismiss();
     const uint32_t id = ctx->next_srs++;

@@ -4,9 +4,15 @@
 
 namespace ty {
 
+// vectors one launch of a pass can carry (typlonk_ntt_fr_batch_devptr): the grid is `count` x the tiles of one vector,
+// tables shared
+constexpr uint32_t NTT_BATCH_MAX = 8;
+
 struct NttPassArgs {
-    const Fr* in;
-    Fr* out;
+    // vector v of the batch: workgroups [v * blocks_per_vec, (v + 1) * blocks_per_vec) read in[v] and write out[v]
+    const Fr* in[NTT_BATCH_MAX];
+    Fr* out[NTT_BATCH_MAX];
+    uint32_t blocks_per_vec;
     uint32_t k;        // log2 of this pass's sub-transform size M
     uint32_t logT;     // log2 of the tile width T
     uint32_t last;     // 1 for the final (contiguous, digit-reversing) pass

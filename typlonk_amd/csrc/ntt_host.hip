@@ -227,8 +227,35 @@ uint32_t ilog2_u64(uint64_t x) {
 
 int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uint64_t* coset_shift, bool sync, const Fr* short_in,
             uint64_t n_valid) {
-    if (log_n > 32) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 32 (Fr two-adicity)");
     if (!d_data) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null data");
+    return ntt_run_batch(ctx, &d_data, 1, log_n, inverse, coset_shift, sync, short_in ? &short_in : nullptr, n_valid);
+}
+
+// `count` transforms of the same size, direction and coset in ONE sequence of pass launches: pass p of every vector is
+// one launch whose grid is count x the tiles of one vector (NttPassArgs::in / out / blocks_per_vec), the tables are shared.
+// The reference always transforms in groups -- the three wire columns (plonk/src/proof.rs:50), their re-evaluation
+// (:113-115), the three sigmas (:334-338, :412-418), the five selectors (plonk/src/builder.rs:84-88) -- and a 2^20
+// transform alone is one round of tiles on the chip (every CU loads, computes and stores in step); a launch with 3 x
+// the tiles lets rounds overlap.  Bit-identical to `count` single calls (the same kernels on the same tiles).
+// More than NTT_BATCH_MAX vectors (or more than the scratch cap) go through in groups.
+int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t log_n, int inverse, const uint64_t* coset_shift,
+                  bool sync, const Fr* const* short_in, uint64_t n_valid) {
+    if (log_n > 32) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 32 (Fr two-adicity)");
+    if (!d_data && count) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null data");
+    for (size_t v = 0; v < count; ++v)
+        if (!d_data[v]) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null data");
+    if (count == 0) return TYPLONK_OK;
+    // vectors per launch: at most NTT_BATCH_MAX, and a multi-pass transform keeps one scratch vector per batch member
+    // (<= 2^26 elements = 2 GiB of scratch in all)
+    size_t group = std::min<size_t>(count, NTT_BATCH_MAX);
+    while (group > 1 && (((uint64_t)group) << log_n) > (1ull << 26)) --group;
+    if (count > group) {
+        int rc = TYPLONK_OK;
+        for (size_t g0 = 0; g0 < count && !rc; g0 += group)
+            rc = ntt_run_batch(ctx, d_data + g0, std::min(group, count - g0), log_n, inverse, coset_shift, sync,
+                               short_in ? short_in + g0 : nullptr, n_valid);
+        return rc;
+    }
     prof_begin(ctx);
     if (log_n == 0) {
         prof_collect(ctx);
@@ -241,7 +268,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
     // (forward only: an inverse 2^20 transform is 4 % faster in three passes of the 30-bit kernel, 0.148 against 0.153 ms)
     // (round 4: the 30-bit kernel reads its sub-transform twiddles from global memory, so 4096 of its 36-byte elements fit
     // the LDS -- 144 KiB -- and it can take the two-pass form too)
-    const bool big = log_n == 20 && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
+    const bool big = log_n == 20 && ctx->ntt_big != 0 && ctx->prover_rounds_active == 0 && ntt_big_tiles_available();
     // log2 of the tile capacity: 4096-element tiles in the first pass of the two-pass 2^20 transform (strided: four columns
     // make 128-byte runs) and 2048 in the last (rows are contiguous, and two workgroups per CU overlap each other's
     // load / compute / store phases: 0.0775 -> 0.070 ms, profiles/r03_ntt_2_20_tiles.txt)
@@ -252,7 +279,7 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
 
     Fr* scratch = nullptr;
     if (P >= 2) {
-        int rc = ensure(ctx, ctx->ntt_scratch, N * sizeof(Fr));
+        int rc = ensure(ctx, ctx->ntt_scratch, count * N * sizeof(Fr));
         if (rc) return rc;
         scratch = (Fr*)ctx->ntt_scratch.p;
     }
@@ -409,21 +436,15 @@ int ntt_run(typlonk_ctx* ctx, Fr* d_data, uint32_t log_n, int inverse, const uin
         if (p == 0 && short_in) {
             a.n_valid = n_valid;
         }
-        if (P == 1) {
-            a.in = short_in ? short_in : d_data;
-            a.out = d_data;
-        } else if (p == 0) {
-            a.in = short_in ? short_in : d_data;
-            a.out = scratch;
-        } else if (!last) {
-            a.in = scratch;
-            a.out = scratch;
-        } else {
-            a.in = scratch;
-            a.out = d_data;
+        for (size_t v = 0; v < count; ++v) {
+            const Fr* src = short_in ? short_in[v] : d_data[v];
+            Fr* scr = scratch ? scratch + v * N : nullptr;
+            a.in[v] = (p == 0) ? src : scr;
+            a.out[v] = last ? d_data[v] : scr;
         }
         const uint64_t E = M << logT;
-        const uint64_t blocks = N / E;
+        a.blocks_per_vec = (uint32_t)(N / E);
+        const uint64_t blocks = (N / E) * count;
         if (f30) {
             a.sub_tw = nullptr;
             a.sub_tw30 = reinterpret_cast<const uint32_t*>(sub30[p].d);
@@ -460,6 +481,24 @@ int typlonk_ntt_fr_devptr(typlonk_ctx* ctx, void* d_data, uint32_t log_n, int in
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     return ntt_run(ctx, (Fr*)d_data, log_n, inverse, coset_shift, /*sync=*/false);
+}
+
+int typlonk_ntt_fr_batch_devptr(typlonk_ctx* ctx, void* const* d_data, size_t count, uint32_t log_n, int inverse,
+                                const uint64_t* coset_shift) {
+    if (!ctx) return TYPLONK_ERR_INVALID_ARG;
+    if (!d_data && count) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    if (log_n > 32) return fail(ctx, TYPLONK_ERR_DOMAIN, "log_n > 32 (Fr two-adicity)");
+    // the vectors are transformed in place and concurrently: two of them must not be the same (or overlapping) storage
+    const uint64_t bytes = sizeof(Fr) << log_n;
+    for (size_t i = 0; i < count; ++i) {
+        if (!d_data[i]) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null data");
+        for (size_t j = 0; j < i; ++j) {
+            const uintptr_t a = (uintptr_t)d_data[i], b = (uintptr_t)d_data[j];
+            if (a < b + bytes && b < a + bytes) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "batched transforms overlap");
+        }
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    return ntt_run_batch(ctx, reinterpret_cast<Fr* const*>(d_data), count, log_n, inverse, coset_shift, /*sync=*/false);
 }
 
 int typlonk_ntt_fr_dev(typlonk_ctx* ctx, typlonk_buf* buf, size_t offset, uint32_t log_n, int inverse,

@@ -172,7 +172,10 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
     Fr* stw = tile + E;
     const uint32_t tid = threadIdx.x;
-    const uint64_t b = blockIdx.x;
+    const uint32_t vec = blockIdx.x / a.blocks_per_vec;   // which vector of the batch (vector-major: tile b of every vector
+    const uint64_t b = blockIdx.x % a.blocks_per_vec;     // lands on the same XCD, whose L2 then holds that tile's twiddles)
+    const Fr* vin = a.in[vec];
+    Fr* vout = a.out[vec];   // (middle passes run in place: vin == vout)
 
     for (uint32_t i = tid; i < (M >> 1); i += NTT_THREADS) ntt_st(stw + i, ntt_ld(a.sub_tw + i));
 
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     auto gload = [&](uint32_t i, uint32_t t) -> Fr {
         const uint64_t g = a.last ? ((k1base + t) * a.Q + q) * M + i : base + (uint64_t)i * a.S + t;
         if (g >= a.n_valid) return Fr::zero();
-        Fr x = ntt_ld(a.in + g);
+        Fr x = ntt_ld(vin + g);
         if (a.pre_full) x = fe_mul(x, ntt_ld(a.pre_full + g));
         else if (a.pre_lo) x = fe_mul(x, ntt_pow2l(a.pre_lo, a.pre_hi, a.pre_h, g));
         return x;
@@ -201,13 +204,13 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
         if (!a.last) {
             if (a.tw_full) x = fe_mul(x, ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t)));
             else x = fe_mul(x, ntt_pow2l(a.tw_lo, a.tw_hi, a.tw_h, (c0 + t) * (uint64_t)kk));
-            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), x);
+            ntt_st(vout + (base + (uint64_t)kk * a.S + t), x);
         } else {
             const uint64_t o = obase + t + a.out_stride * kk;
             if (a.post_full) x = fe_mul(x, ntt_ld(a.post_full + o));
             else if (a.post_lo) x = fe_mul(x, ntt_pow2l(a.post_lo, a.post_hi, a.post_h, o));
             if (a.scale) x = fe_mul(x, ntt_ld(a.scale));
-            ntt_st(a.out + o, x);
+            ntt_st(vout + o, x);
         }
     };
     const bool direct = k >= 2;   // (k = 1: a single radix-2 stage through the LDS tile)
@@ -261,7 +264,10 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     uint32_t* tile = reinterpret_cast<uint32_t*>(ntt_smem);
     const uint32_t* stw = a.sub_tw30;   // global memory (NttArith30::ldtw)
     const uint32_t tid = threadIdx.x;
-    const uint64_t b = blockIdx.x;
+    const uint32_t vec = blockIdx.x / a.blocks_per_vec;   // (as in ntt_pass_kernel)
+    const uint64_t b = blockIdx.x % a.blocks_per_vec;
+    const Fr* vin = a.in[vec];
+    Fr* vout = a.out[vec];   // (middle passes run in place: vin == vout)
 
     uint64_t base = 0, c0 = 0, q = 0, k1base = 0, obase = 0;
     if (!a.last) {
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     auto gload = [&](uint32_t i, uint32_t t) -> Fr30 {
         const uint64_t g = a.last ? ((k1base + t) * a.Q + q) * M + i : base + (uint64_t)i * a.S + t;
         if (g >= a.n_valid) return fr30_unpack(Fr::zero());
-        Fr30 x = fr30_unpack(ntt_ld(a.in + g));
+        Fr30 x = fr30_unpack(ntt_ld(vin + g));
         if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
         return x;
     };
@@ -285,13 +291,13 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
         const uint32_t kk = (k ? (__brev(i) >> (32 - k)) : 0u);
         if (!a.last) {
             x = fr30_mul(x, fr30_unpack(ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t))));
-            ntt_st(a.out + (base + (uint64_t)kk * a.S + t), fr30_pack(x));  // < 2r: the next pass takes it as it is
+            ntt_st(vout + (base + (uint64_t)kk * a.S + t), fr30_pack(x));  // < 2r: the next pass takes it as it is
         } else {
             const uint64_t o = obase + t + a.out_stride * kk;
             if (a.post_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.post_full + o)));
             else if (a.scale) x = fr30_mul(x, fr30_unpack(ntt_ld(a.scale)));
             else x = fr30_reduce_lazy(x);   // no factor to fold the reduction into: one quotient estimate instead of a multiplication
-            ntt_st(a.out + o, fr30_to_canonical(x));
+            ntt_st(vout + o, fr30_to_canonical(x));
         }
     };
     const bool direct = k >= 2;   // (k = 1: a single radix-2 stage through the LDS tile)

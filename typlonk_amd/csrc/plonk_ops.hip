@@ -8,8 +8,9 @@
 // All three are scans over Fr.  The grand product avoids the reference's one field division per cell:
 //   Z_j = prod_{k<j} num_k / prod_{k<j} den_k = N_j * S_j * S_0^-1,
 // N = exclusive prefix products of the numerators, S_j = prod_{k>=j} den_k (suffix products), so one
-// inversion (of S_0, on the host) serves the whole column.  Field arithmetic is exact, so every Z_j is
+// inversion (of S_0, on the device: fr_inv_kernel) serves the whole column.  Field arithmetic is exact, so every Z_j is
 // the same field element the reference computes.
+#include "fr_inv.hpp"
 #include "launch.hpp"
 
 namespace ty {
@@ -127,11 +128,17 @@ __global__ __launch_bounds__(256) void pscan_finish_kernel(const Fr* in, uint64_
     }
 }
 
+// out[0] = in[0]^-1 (0 -> 0): one wavefront, every lane the same value -- the ONE inversion of a proof's grand product
+// (fr_inv.hpp: divsteps, ~20 rounds of 30), on the device so that round 2 never drains the stream for it
+__global__ __launch_bounds__(64) void fr_inv_kernel(const Fr* in, Fr* out) {
+    const Fr x = fr_inv_divsteps(p_ld(in));
+    if (threadIdx.x == 0) p_st(out, x);
+}
 // Z_j = N_j * S_j * inv_total
-__global__ __launch_bounds__(256) void gp_finish_kernel(const Fr* nprefix, const Fr* dsuffix, Fr inv_total, uint64_t n, Fr* z) {
+__global__ __launch_bounds__(256) void gp_finish_kernel(const Fr* nprefix, const Fr* dsuffix, const Fr* inv_total, uint64_t n, Fr* z) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    p_st(z + j, fe_mul(fe_mul(p_ld(nprefix + j), p_ld(dsuffix + j)), inv_total));
+    p_st(z + j, fe_mul(fe_mul(p_ld(nprefix + j), p_ld(dsuffix + j)), p_ld(inv_total)));
 }
 
 // ---- open(): H_j = c_j + z H_{j+1} (H_m = 0) for all j at once ------------------------------------------
@@ -338,7 +345,8 @@ void launch_product_scan(const Fr* in, uint64_t n, int reverse, Fr* block_scratc
     hipLaunchKernelGGL(pscan_top_kernel, dim3(1), dim3(256), 0, s, block_scratch, nblk);
     hipLaunchKernelGGL(pscan_finish_kernel, dim3(nblk), dim3(256), 0, s, in, n, reverse, block_scratch, out);
 }
-void launch_gp_finish(const Fr* nprefix, const Fr* dsuffix, const Fr& inv_total, uint64_t n, Fr* z, hipStream_t s) {
+void launch_fr_inv(const Fr* in, Fr* out, hipStream_t s) { hipLaunchKernelGGL(fr_inv_kernel, dim3(1), dim3(64), 0, s, in, out); }
+void launch_gp_finish(const Fr* nprefix, const Fr* dsuffix, const Fr* inv_total, uint64_t n, Fr* z, hipStream_t s) {
     hipLaunchKernelGGL(gp_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, nprefix, dsuffix, inv_total, n, z);
 }
 

@@ -30,6 +30,10 @@ int quotient_extend(typlonk_ctx* ctx, Fr* e, const Fr* src, const Fr* fill, uint
     HIPCHK(hipMemsetAsync(e + n, 0, 3 * n * sizeof(Fr), s));
     return ntt_run(ctx, e, log4, 0, quotient_coset_g(nullptr), /*sync=*/false);
 }
+// the same for `count` coefficient vectors at once (one launch per pass for the whole group)
+int quotient_extend_batch(typlonk_ctx* ctx, Fr* const* e, const Fr* const* src, size_t count, uint64_t n, uint32_t log4) {
+    return ntt_run_batch(ctx, e, count, log4, 0, quotient_coset_g(nullptr), /*sync=*/false, src, n);
+}
 }  // namespace
 
 int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5], const typlonk_buf* const sigma[3],
@@ -57,9 +61,19 @@ int typlonk_circuit_load(typlonk_ctx* ctx, const typlonk_buf* const selectors[5]
     ProfilingOff prof_off(ctx);  // stage events are per call
     int rc = TYPLONK_OK;
     const Fr ninv = fe_inv(fr_from_u64(n));
-    for (int k = 0; k < 9 && !rc; ++k)
-        rc = quotient_extend(ctx, e.ext + (uint64_t)k * n4, k < 8 ? in[k]->d : nullptr, &ninv, n, log_n + 2);
-    for (int k = 0; k < 3 && !rc; ++k) rc = ntt_run(ctx, e.sig_ev + (uint64_t)k * n, log_n, 0, nullptr, /*sync=*/false);
+    {
+        // the eight coefficient vectors (builder.rs:84-88's five selectors, the three sigmas) as one batch, then L0
+        Fr* dst[8];
+        const Fr* src[8];
+        for (int k = 0; k < 8; ++k) {
+            dst[k] = e.ext + (uint64_t)k * n4;
+            src[k] = in[k]->d;
+        }
+        rc = quotient_extend_batch(ctx, dst, src, 8, n, log_n + 2);
+        if (!rc) rc = quotient_extend(ctx, e.ext + 8 * n4, nullptr, &ninv, n, log_n + 2);
+        Fr* sig[3] = {e.sig_ev, e.sig_ev + n, e.sig_ev + 2 * n};
+        if (!rc) rc = ntt_run_batch(ctx, sig, 3, log_n, 0, nullptr, /*sync=*/false);   // proof.rs:334-338
+    }
     if (!rc) {
         hipError_t he = hipStreamSynchronize(ctx->stream);
         if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
@@ -232,10 +246,11 @@ int typlonk_grand_product_dev(typlonk_ctx* ctx, const typlonk_buf* const wires[3
     launch_product_scan(num, n, 0, blk, npre, s);
     launch_product_scan(den, n, 1, blk, dsuf, s);
     HIPCHK(hipGetLastError());
-    Fr total;
-    HIPCHK(hipMemcpyAsync(&total, dsuf, sizeof(Fr), hipMemcpyDeviceToHost, s));  // S_0 = prod of all denominators
-    HIPCHK(hipStreamSynchronize(s));
-    launch_gp_finish(npre, dsuf, fe_inv(total), n, z_evals_out->d, s);
+    // S_0 = dsuf[0] = the product of all denominators: inverted ON THE DEVICE (fr_inv.hpp) into the slot behind the carries
+    // -- no copy, no wait, no host inversion between the scans and the finish (rounds 1-5 drained the stream here)
+    Fr* inv_total = blk + nblk;
+    launch_fr_inv(dsuf, inv_total, s);
+    launch_gp_finish(npre, dsuf, inv_total, n, z_evals_out->d, s);
     HIPCHK(hipGetLastError());
     return TYPLONK_OK;
 }
@@ -323,6 +338,19 @@ int prover_extend(typlonk_prover* p, int k, const Fr* coeffs) {
     if (!rc) p->extended |= 1u << k;
     return rc;
 }
+// the same for several inputs at once (ks[]: their slots): one launch per pass for the group
+int prover_extend_batch(typlonk_prover* p, const int* ks, const Fr* const* coeffs, size_t count) {
+    typlonk_ctx* ctx = p->ctx;
+    const uint64_t n4 = 4 * p->n;
+    int rc = ensure(ctx, ctx->quot_ext, (size_t)5 * n4 * sizeof(Fr));
+    if (rc) return rc;
+    Fr* dst[5];
+    for (size_t i = 0; i < count; ++i) dst[i] = (Fr*)ctx->quot_ext.p + (uint64_t)ks[i] * n4;
+    rc = quotient_extend_batch(ctx, dst, coeffs, count, p->n, p->log_n + 2);
+    if (!rc)
+        for (size_t i = 0; i < count; ++i) p->extended |= 1u << ks[i];
+    return rc;
+}
 // ops_tmp layout of the prover's openings: [0, 8*2048) per-workgroup carries, then 16 result slots
 constexpr size_t PROVER_EVAL_BLOCKS = 8 * 2048;
 int prover_ops_tmp(typlonk_prover* p, Fr** blocks, Fr** slots) {
@@ -406,21 +434,37 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
         return e == hipSuccess ? TYPLONK_OK : fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(e));
     };
     MsmQueue q(ctx, srs, /*first_lane=*/1);
-    for (int i = 0; i < 3 && !rc; ++i) {
-        if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
-        if ((rc = d2d(p->co[i], wire_evals[i]->d))) break;
-        if ((rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false))) break;
-        rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
-    }
     p->has_pi = pi_evals != nullptr;  // NULL: public inputs [0] -> the zero polynomial
-    if (!rc && p->has_pi) {
-        rc = d2d(p->pi, pi_evals->d);
-        if (!rc) rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
+    if (ctx->prover_ntt_batch) {
+        // the three interpolations (and the public-input column's, proof.rs:105-106) as ONE batched transform
+        // (ntt_run_batch), then the three commitments, then the coset extensions of the same group as one batch
+        for (int i = 0; i < 3 && !rc; ++i) {
+            if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
+            rc = d2d(p->co[i], wire_evals[i]->d);
+        }
+        if (!rc && p->has_pi) rc = d2d(p->pi, pi_evals->d);
+        Fr* grp[4] = {p->co[0], p->co[1], p->co[2], p->pi};
+        const size_t cnt = p->has_pi ? 4 : 3;
+        if (!rc) rc = ntt_run_batch(ctx, grp, cnt, log_n, 1, nullptr, false);
+        for (int i = 0; i < 3 && !rc; ++i) rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
+        const int slots[4] = {0, 1, 2, 4};
+        if (!rc) rc = prover_extend_batch(p, slots, grp, cnt);
+    } else {
+        for (int i = 0; i < 3 && !rc; ++i) {
+            if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
+            if ((rc = d2d(p->co[i], wire_evals[i]->d))) break;
+            if ((rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false))) break;
+            rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
+        }
+        if (!rc && p->has_pi) {
+            rc = d2d(p->pi, pi_evals->d);
+            if (!rc) rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
+        }
+        // the coset transforms of the quotient's per-proof inputs run beside the commitments (measured: -1 % per proof;
+        // submitting round 3's first opening MSMs before the quotient loses 1 %: profiles/r02_ab_prover_overlap.txt)
+        for (int i = 0; i < 3 && !rc; ++i) rc = prover_extend(p, i, p->co[i]);
+        if (!rc && p->has_pi) rc = prover_extend(p, 4, p->pi);
     }
-    // the coset transforms of the quotient's per-proof inputs run beside the commitments (measured: -1 % per proof;
-    // submitting round 3's first opening MSMs before the quotient loses 1 %: profiles/r02_ab_prover_overlap.txt)
-    for (int i = 0; i < 3 && !rc; ++i) rc = prover_extend(p, i, p->co[i]);
-    if (!rc && p->has_pi) rc = prover_extend(p, 4, p->pi);
     {
         const int r = q.wait_all();
         if (!rc) rc = r;

@@ -103,12 +103,17 @@ __global__ __launch_bounds__(64) void srs_tables_kernel(uint32_t* pts, uint32_t*
     a.y = p.y;
     a.z = fq30_one();                                   // the identity walks along as a harmless non-point
     Fq30 run = fq30_one();
+    uint32_t dead_from = inf ? 1u : T;                  // first table whose entry is the identity (T: none)
     for (uint32_t t = 1; t < T; ++t) {
         for (uint32_t d = 0; d < c; ++d) a = g1_jac_dbl(a);
-        // a denominator that vanishes (an input that is not a point of odd order) is taken out of the product: the entry
-        // becomes the identity
+        // a denominator that vanishes (an input that is not a point of odd order -- only typlonk_srs_load can bring one,
+        // it does not validate) is taken out of the product; 2^k * identity = identity, so that entry AND every later one
+        // of the column are the identity (the chain itself walks on from a harmless non-point)
         const bool zero = fq30_is_zero_mod(a.z);
-        if (zero) a.z = fq30_one();
+        if (zero) {
+            a.z = fq30_one();
+            dead_from = min(dead_from, t);
+        }
         if (live) {
             uint32_t* dst = pts + (t * len + i) * PT_WORDS;
             st_fq(dst, zero ? fq30_zero() : a.x);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(64) void srs_tables_kernel(uint32_t* pts, uint32_t*
         e.x = ld_fq(dst);
         e.y = ld_fq(dst + 12);
         G1Affine r = g1_jac_to_affine_with(e, zinv);
-        if (inf) r = G1Affine::inf();
+        if (t >= dead_from) r = G1Affine::inf();
         st_fq(dst, r.x);
         st_fq(dst + 12, r.y);
     }
