@@ -75,9 +75,10 @@ constexpr size_t HOST_WIN_POINTS = 32 * 2 * RC_NB;  // up to 32 bucket sets x {r
 // Outputs of the bucket sort of one chunk of terms; a workspace owns two sets so that the sort of chunk k + 1 can run
 // (on the workspace's side stream) while chunk k is being accumulated.
 struct SortBufs {
-    DevBuf keys, sorted, counts, offsets, cursor, blocksums, order, ohist, blk_hist, blk_base, heavy, tasks, hpart;
+    DevBuf keys, sorted, counts, offsets, cursor, blocksums, order, ohist, blk_hist, blk_base, blk_cnt, seg_start, heavy, tasks, hpart;
     std::vector<DevBuf*> all() {
-        return {&keys, &sorted, &counts, &offsets, &cursor, &blocksums, &order, &ohist, &blk_hist, &blk_base, &heavy, &tasks, &hpart};
+        return {&keys, &sorted, &counts, &offsets, &cursor, &blocksums, &order, &ohist, &blk_hist, &blk_base, &blk_cnt, &seg_start,
+                &heavy, &tasks, &hpart};
     }
 };
 constexpr int MSM_MAX_CHUNKS = 8;
@@ -121,11 +122,12 @@ struct typlonk_buf {
 //   TYPLONK_MSM_CHAIN     0 | 1: the lanes of a batch run free / chain their accumulations (default: by term count)
 //   TYPLONK_MSM_CHUNKS    chunks of a stand-alone MSM (0 = by length)
 //   TYPLONK_MSM_LANES     lanes per bucket of the accumulation (1, 2, 4, 8, 16; 0 = by bucket load)
+//   TYPLONK_MSM_SCATTER   staged | direct: level 1 of the bucket sort stages its runs in the LDS / writes entry by entry
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
 //   TYPLONK_NTT_FR30      0 | 1 | 2: the 9 x 30-bit butterflies never / where they measure faster / always
 //   TYPLONK_NTT_BIG       0 | 1 | 2: the two-pass 2^20 plan (4096-element tiles) never / where it measures faster / always
-//   TYPLONK_PROVER_NTT_BATCH 0 | 1: round 1 transforms its columns one by one (each commitment submitted as soon as its
-//                         polynomial exists) / as one batched transform per group (ntt_run_batch)
+//   TYPLONK_PROVER_NTT_BATCH 0 | 1 | 2: round 1 transforms its columns one by one (each commitment submitted as soon as its
+//                         polynomial exists) / as one batched transform per group (ntt_run_batch) / the first alone, the rest batched
 //   TYPLONK_PROVER_PIPE   0 | 1: round 3's nine commitments queued as in rounds 1-4 / behind one fence (prover_round3_core)
 // (TYPLONK_RCCL_LIB, read by comm.hip, names the RCCL library to load.)
 struct typlonk_ctx {
@@ -162,10 +164,13 @@ struct typlonk_ctx {
     // 0.419 -> 0.464 ms per MSM -- so the switch sits below the shard size; from 2^19 on the chain is never worse and
     // 2^20 needs it.  -1 = by term count (MSM_CHAIN_MIN_TERMS), 0 / 1 = TYPLONK_MSM_CHAIN.
     int msm_chain = -1;
-    bool prover_ntt_batch = true;  // TYPLONK_PROVER_NTT_BATCH: round 1's interpolations / coset extensions as batched transforms
+    int prover_ntt_batch = 2;      // TYPLONK_PROVER_NTT_BATCH: round 1's interpolations / coset extensions 0 = one by one, 1 = one batch
+                                   // per group, 2 = the first column alone (its commitment starts at once), the rest batched
     bool prover_pipe = true;       // TYPLONK_PROVER_PIPE (A/B switch of the round-5 queueing fix, prover_round3_core)
     int msm_chunks = 0;            // chunks of a stand-alone MSM (0 = choose by length)
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
+    bool msm_scatter_staged = true;  // TYPLONK_MSM_SCATTER=direct: level 1 of the bucket sort writes every entry straight to global
+                                   // memory (the rounds 1-5 form, the A/B reference) instead of staging runs in the LDS
     bool msm_rc4 = false;          // always the four-launch row/column reduction
     bool msm_rc2_force = false;    // the two-launch form for every bucket-set size
     // NTT

@@ -89,10 +89,13 @@ void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, ui
 void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor,
                  hipStream_t s);
 uint32_t msm_segsort_blocks(uint64_t m);  // workgroups of the level-1 passes for an m-term MSM
+// the whole segmented bucket sort of one chunk, bucket schedule (order[]) included; blk_cnt: nseg * nblk words (the staged
+// level-1 scatter's per-workgroup count rows; NULL = direct scatter), seg_start: 2 * nseg words
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
-                        uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
-                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, bool centred, hipStream_t s);
+                        uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries, uint32_t* counts,
+                        uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks,
+                        uint32_t* order, bool centred, int staged_mode, hipStream_t s);
 // windows of the signed c-bit digit decomposition.  Scalars are canonical (< r < 2^255): the top window holds
 // t = bits - c (W0 - 1) bits, W0 = ceil(bits / c), and a digit <= 2^t cannot exceed 2^(c-1) (no carry out of it) unless
 // t = c.  Centred scalars (|k| <= (r - 1)/2 < 2^254) have one bit less: c = 17 -> 15 windows instead of 16.
@@ -105,7 +108,7 @@ TY_HD uint32_t msm_windows(uint32_t c, bool centred) {
 size_t srs_tables_scratch_bytes(uint64_t len, uint32_t T);
 void launch_srs_tables(uint32_t* pts, uint32_t* zbuf, uint64_t len, uint32_t c, uint32_t T, hipStream_t s);
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
-                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, bool hist_done, hipStream_t s);
+                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, hipStream_t s);
 void launch_msm_heavy(const uint32_t* points, const uint32_t* sorted, const uint32_t* hist516, uint32_t* heavy,
                       const uint32_t* tasks, uint32_t* partial, uint32_t* buckets, hipStream_t s);
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,

@@ -179,13 +179,16 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if (segsort) {
             if ((rc = ensure(ctx, sb.blk_hist, seg.nmat * 4))) return rc;
             if ((rc = ensure(ctx, sb.blk_base, (seg.nmat + 1) * 4))) return rc;
+            if ((rc = ensure(ctx, sb.blk_cnt, seg.nmat * 4))) return rc;
+            if ((rc = ensure(ctx, sb.seg_start, seg.nseg * 8))) return rc;
             if ((rc = ensure(ctx, sb.blocksums, (size_t)((seg.nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks + seg.nseg) * 4))) return rc;
             blocksums = (uint32_t*)sb.blocksums.p;
             StageTimer st(ctx, ss == s ? "msm_sort" : "msm_sort_overlapped", ss);
             launch_msm_segsort(sc, (uint64_t)mk, c, W, digit_v, (uint32_t)seg.hb, seg.ibits, tables ? (uint32_t)srs.len : 0u,
-                               tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums, keys,
-                               counts, offsets, sorted, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p,
-                               (uint32_t*)sb.tasks.p, centred, ss);
+                               tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums,
+                               (uint32_t*)sb.blk_cnt.p, (uint32_t*)sb.seg_start.p, keys, counts, offsets, sorted, cap,
+                               (uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, (uint32_t*)sb.order.p,
+                               centred, ctx->msm_scatter_staged ? 1 : 0, ss);
         } else {
             {
                 StageTimer st(ctx, "msm_digits", ss);
@@ -201,21 +204,19 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
                 launch_msm_scatter(keys, (uint64_t)mk, total, cursor, sorted, ss);
             }
         }
-        // The bucket schedule of an overlapped chunk is built on the MSM's own stream, behind the previous accumulation:
-        // the overlapped sort ends about when that accumulation does (it only gets the slots the accumulation leaves),
-        // so on the side stream the schedule kernel was one more cross-stream hand-over on the critical path
-        // (same-box A/B, profiles/r05_ab_order_on_main.txt: 2.632 -> 2.592 ms per stand-alone 2^20 MSM, 2^22 unchanged)
-        const bool order_main = ss != s;
-        if (order_main) {
+        // The segmented sort ends with the bucket schedule (order[], msm_seg_place_kernel); only the atomic sort of the
+        // shapes it cannot take needs the separate schedule launches.
+        if (!segsort) {
+            StageTimer st(ctx, "msm_order", ss);
+            launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.order.p,
+                                (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, ss);
+        }
+        if (ss != s) {   // an overlapped chunk: the accumulation on the MSM's stream waits for the side stream's sort
             HIPCHK(hipEventRecord(ws.ev_sorted[k], ss));
             HIPCHK(hipStreamWaitEvent(s, ws.ev_sorted[k], 0));
+        } else if (nch > 1 && k == 0) {
+            HIPCHK(hipEventRecord(ws.ev_sorted[0], s));
         }
-        {
-            StageTimer st(ctx, "msm_order", s);
-            launch_bucket_order(counts, offsets, (uint32_t)nb_used, cap, (uint32_t*)sb.ohist.p, (uint32_t*)sb.order.p,
-                                (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, /*hist_done=*/segsort, s);
-        }
-        if (!order_main && nch > 1 && k == 0) HIPCHK(hipEventRecord(ws.ev_sorted[0], s));
         {
             // lanes per bucket: a short MSM over a small bucket set has few, long buckets -- spread each over L lanes so
             // that the launch fills the chip twice over (>= 2^18 threads: two rounds of two wavefronts per SIMD balance the

@@ -189,6 +189,14 @@ struct MsmShape {
     uint32_t centred;
 };
 
+// Column of workgroup `blk` in the workgroup x segment matrix = its place inside every segment's output range.
+// Workgroups are dealt to the eight XCDs round-robin (blk mod 8), each XCD with its own L2: with the columns ordered by
+// XCD first, the runs that are NEIGHBOURS in memory come from workgroups that share an L2, so a cache line that two runs
+// straddle is completed there instead of leaving two L2s as two partial writes.
+__device__ __forceinline__ uint32_t msm_seg_col(const MsmShape& sh, uint32_t blk) {
+    return (sh.nblk & 7u) ? blk : (blk & 7u) * (sh.nblk >> 3) + (blk >> 3);
+}
+
 __device__ __forceinline__ uint32_t msm_seg_of(const MsmShape& sh, uint32_t j, uint32_t b) {
     if (sh.tlen) return b >> sh.lb;
     return (j << sh.hb) | (b >> sh.lb);
@@ -212,6 +220,41 @@ __device__ __forceinline__ void msm_for_each_digit(const uint32_t (&v)[8], const
         if (d != 0) {
             const uint32_t b = (j + 1 == sh.W) ? ((d - 1) << sh.top_v) + (i & ((1u << sh.top_v) - 1)) : d - 1;
             emit(j, b, neg);
+        }
+    }
+}
+
+// The same with the window width a compile-time constant (the table windows 15 / 17 / 20): bit offsets, word indices and
+// shifts fold into the instructions -- one funnel shift and a mask per digit where the run-time form selects two words
+// out of eight (16 compares + selects) and shifts 64 bits: ~10 instead of ~50 instructions per digit, 13-18 digits per
+// scalar, in BOTH level-1 passes.  C = 0: the run-time form.
+template <uint32_t C, class F>
+__device__ __forceinline__ void msm_for_each_digit_c(const uint32_t (&v)[8], const MsmShape& sh, uint32_t i, F&& emit) {
+    if constexpr (C == 0) {
+        msm_for_each_digit(v, sh, i, emit);
+    } else {
+        constexpr uint32_t WMAX = (256 + C - 1) / C;
+        constexpr uint32_t B = 1u << (C - 1);
+        uint32_t carry = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < WMAX; ++j) {
+            if (j < sh.W) {
+                const uint32_t o = j * C, w = o >> 5, sft = o & 31;
+                uint32_t x = v[w] >> sft;
+                if (sft + C > 32 && w + 1 < 8) x |= v[w + 1] << (32 - sft);
+                uint32_t d = (x & ((1u << C) - 1)) + carry;
+                uint32_t neg = 0;
+                carry = 0;
+                if (d > B) {
+                    d = (1u << C) - d;
+                    neg = 1;
+                    carry = 1;
+                }
+                if (d != 0) {
+                    const uint32_t b = (j + 1 == sh.W) ? ((d - 1) << sh.top_v) + (i & ((1u << sh.top_v) - 1)) : d - 1;
+                    emit(j, b, neg);
+                }
+            }
         }
     }
 }
@@ -240,8 +283,10 @@ __device__ __forceinline__ uint32_t msm_load_canon(const Fr* scalars, uint64_t i
     return flip;
 }
 
+// blk_cnt != nullptr: also the workgroup's own row of counts, contiguous (the staged scatter scans it for its LDS layout)
+template <uint32_t C>
 __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
-                                                            uint32_t* blk_hist) {
+                                                            uint32_t* blk_hist, uint32_t* blk_cnt) {
     extern __shared__ uint32_t seg_h[];
     const uint32_t nt = blockDim.x;
     for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) seg_h[s] = 0;
@@ -252,13 +297,18 @@ __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, u
         if (i < m) {
             uint32_t v[8];
             (void)msm_load_canon(scalars, i, sh.centred, v);
-            msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t) {
+            msm_for_each_digit_c<C>(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t) {
                 atomicAdd(&seg_h[msm_seg_of(sh, j, b)], 1u);
             });
         }
     }
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) blk_hist[(uint64_t)s * sh.nblk + blockIdx.x] = seg_h[s];
+    const uint32_t col = msm_seg_col(sh, blockIdx.x);
+    for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) {
+        const uint32_t n = seg_h[s];
+        blk_hist[(uint64_t)s * sh.nblk + col] = n;
+        if (blk_cnt) blk_cnt[(uint64_t)blockIdx.x * sh.nseg + s] = n;
+    }
 }
 
 // One launch instead of the three of the exclusive scan over the whole workgroup x segment matrix (short MSMs: three
@@ -320,17 +370,21 @@ __device__ __forceinline__ void msm_seg_starts(const uint32_t* __restrict__ seg_
 }
 
 // seg_tot == nullptr: blk_base holds absolute positions (the three-launch scan); else row prefixes + segment totals
+// (the direct form: every entry goes straight to its place in global memory, 4 bytes at a time.  Kept for the shapes whose
+// staging area does not fit the LDS; the staged form below is the one the table-mode MSMs take)
+template <uint32_t C>
 __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
                                                                const uint32_t* blk_base, const uint32_t* seg_tot,
                                                                uint32_t* entries) {
     extern __shared__ uint32_t seg_sm[];
     uint32_t* cur = seg_sm;             // running position of this workgroup inside each segment
     const uint32_t nt = blockDim.x;
+    const uint32_t col = msm_seg_col(sh, blockIdx.x);
     if (seg_tot) {
         msm_seg_starts(seg_tot, sh.nseg, cur, seg_sm + sh.nseg);
-        for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] += blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
+        for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] += blk_base[(uint64_t)s * sh.nblk + col];
     } else {
-        for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] = blk_base[(uint64_t)s * sh.nblk + blockIdx.x];
+        for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] = blk_base[(uint64_t)s * sh.nblk + col];
     }
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
@@ -340,7 +394,7 @@ __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars
         if (i < m) {
             uint32_t v[8];
             const uint32_t flip = msm_load_canon(scalars, i, sh.centred, v);
-            msm_for_each_digit(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
+            msm_for_each_digit_c<C>(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
                 const uint32_t pos = atomicAdd(&cur[msm_seg_of(sh, j, b)], 1u);
                 neg ^= flip;
                 entries[pos] = (uint32_t)i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
@@ -350,18 +404,77 @@ __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars
     }
 }
 
-// one workgroup per segment: count by low bits, local exclusive scan -> bucket counts/offsets,
-// then the final scatter.  The segment is read twice from L2; only a 256-bin histogram lives in LDS,
-// so any segment length works.
-// It also does what order_hist_kernel does for its own 2^lb buckets (their sizes are in registers here): the size
-// histogram of the bucket schedule and the task lists of heavy buckets -- one launch and one pass over counts[] fewer.
-__global__ __launch_bounds__(1024) void msm_seg_sort_kernel(const uint32_t* __restrict__ entries,
-                                                            const uint32_t* __restrict__ blk_base,
-                                                            const uint32_t* __restrict__ seg_tot, MsmShape sh,
-                                                            uint32_t total_slot, uint32_t* counts, uint32_t* offsets,
-                                                            uint32_t* sorted, uint32_t cap, uint32_t* ohist, uint32_t* heavy,
-                                                            uint32_t* tasks) {
-    // 256, 512 or 1024 threads: all of them walk the segment, the first 256 own the 2^lb <= 256 buckets
+// The staged form (round 6).  The direct form above writes 4 bytes wherever an entry belongs: W entries per scalar into
+// nseg different runs, each run of a workgroup ~13 entries long and filled over the whole lifetime of the kernel -- the
+// lines leave the L2 partially written (profiles/r05_pmc_traffic.json: 168,821 KiB written for 27 MB of entries, 6.2 x).
+// Here the workgroup first counting-sorts its entries by segment INSIDE the LDS -- its own row of the count matrix
+// (blk_cnt, from the histogram pass) scanned gives every segment's place in the staging area, an LDS atomic the rank --
+// and then copies every run out in one piece: a quarter wavefront (16 lanes) per run, so a store instruction covers four
+// runs of <= 64 contiguous bytes, and a run's cache lines are written once.
+// LDS: nseg running ranks | nseg local starts | nseg global starts | the staging area (chunk * W entries).
+template <uint32_t C>
+__global__ __launch_bounds__(256) void msm_seg_scatter_staged_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
+                                                                     const uint32_t* __restrict__ blk_base,
+                                                                     const uint32_t* __restrict__ seg_tot,
+                                                                     const uint32_t* __restrict__ blk_cnt, uint32_t* entries) {
+    extern __shared__ uint32_t seg_sm[];
+    uint32_t* rank = seg_sm;
+    uint32_t* loc = seg_sm + sh.nseg;
+    uint32_t* gst = seg_sm + 2 * sh.nseg;
+    uint32_t* stage = seg_sm + 3 * sh.nseg;
+    const uint32_t nt = blockDim.x, tid = threadIdx.x;
+    const uint32_t col = msm_seg_col(sh, blockIdx.x);
+    // global start of this workgroup's run in every segment; local start of every segment in the staging area
+    // (the staging area doubles as the scans' scratch: nothing is staged yet)
+    msm_seg_starts(seg_tot, sh.nseg, gst, stage);
+    msm_seg_starts(blk_cnt + (uint64_t)blockIdx.x * sh.nseg, sh.nseg, loc, stage);
+    for (uint32_t s = tid; s < sh.nseg; s += nt) {
+        gst[s] += blk_base[(uint64_t)s * sh.nblk + col];
+        rank[s] = 0;
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
+    const uint32_t lmask = (1u << sh.lb) - 1;
+    for (uint32_t e = 0; e < sh.chunk / nt; ++e) {
+        const uint64_t i = base + tid + nt * e;
+        if (i < m) {
+            uint32_t v[8];
+            const uint32_t flip = msm_load_canon(scalars, i, sh.centred, v);
+            msm_for_each_digit_c<C>(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
+                const uint32_t sg = msm_seg_of(sh, j, b);
+                const uint32_t r = atomicAdd(&rank[sg], 1u);
+                neg ^= flip;
+                stage[loc[sg] + r] = (uint32_t)i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
+                                     ((b & lmask) << (sh.ibits + sh.jbits + 1));
+            });
+        }
+    }
+    __syncthreads();
+    // copy-out: quarter wavefront q takes segments q, q + nt/16, ...; rank[] now holds the run lengths
+    const uint32_t q = tid >> 4, l = tid & 15u, nq = nt >> 4;
+    for (uint32_t sg = q; sg < sh.nseg; sg += nq) {
+        const uint32_t len = rank[sg], src = loc[sg], dst = gst[sg];
+        for (uint32_t k = l; k < len; k += 16) entries[dst + k] = stage[src + k];
+    }
+}
+
+// Level 2, one workgroup per segment, in two launches around the one global dependency of the bucket schedule (the size
+// histogram over ALL buckets must be complete before any bucket can be placed in the size-sorted order):
+//   msm_seg_count_kernel  count the segment's entries by their low bits -> counts[], offsets[] of its 2^lb buckets, the
+//                         size histogram (hist514[0..255]) and the task lists of heavy buckets (what order_hist_kernel
+//                         does for the atomic sort); publishes the segment's start for the second launch.
+//   msm_seg_place_kernel  re-read the segment (L2), rank every entry inside its bucket with an LDS atomic and write the
+//                         final `sorted` array -- AND place the segment's buckets into order[] (what order_fused_kernel did in
+//                         a launch of its own, 27 us of latency per accumulation launch: every workgroup scans the complete
+//                         256-bin histogram for itself and claims its run inside each bin from a global cursor).  The claim's
+//                         round trip to the L2 hides under the placement loop.
+// 256, 512 or 1024 threads: all of them walk the segment, the first 256 own the 2^lb <= 256 buckets.
+__global__ __launch_bounds__(1024) void msm_seg_count_kernel(const uint32_t* __restrict__ entries,
+                                                             const uint32_t* __restrict__ blk_base,
+                                                             const uint32_t* __restrict__ seg_tot, MsmShape sh,
+                                                             uint32_t total_slot, uint32_t* counts, uint32_t* offsets,
+                                                             uint32_t* seg_start, uint32_t cap, uint32_t* ohist, uint32_t* heavy,
+                                                             uint32_t* tasks) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t pref[256];
     __shared__ uint32_t red[1024];
@@ -382,6 +495,10 @@ __global__ __launch_bounds__(1024) void msm_seg_sort_kernel(const uint32_t* __re
         start = blk_base[(uint64_t)s * sh.nblk];
         end = (s + 1 < sh.nseg) ? blk_base[(uint64_t)(s + 1) * sh.nblk] : blk_base[total_slot];
     }
+    if (tid == 0) {
+        seg_start[2 * s] = start;
+        seg_start[2 * s + 1] = end;
+    }
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const uint32_t low_sh = sh.ibits + sh.jbits + 1;
@@ -398,10 +515,7 @@ __global__ __launch_bounds__(1024) void msm_seg_sort_kernel(const uint32_t* __re
     }
     const uint32_t excl = tid < 256 ? pref[tid] - mine : 0;
     __syncthreads();
-    if (tid < 256) {
-        pref[tid] = excl;
-        hist[tid] = 0;
-    }
+    if (tid < 256) hist[tid] = 0;
     const uint32_t nlow = 1u << sh.lb;
     if (tid < nlow) {
         const uint32_t bucket = s * nlow + tid;
@@ -428,26 +542,63 @@ __global__ __launch_bounds__(1024) void msm_seg_sort_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    // schedule histogram (what order_hist_kernel would count for these buckets): size bins in `hist`, which is the
-    // scatter's counter array afterwards and is cleared again before the scatter
+    // schedule histogram: size bins of this segment's buckets, one global atomic per occupied bin
     if (tid < nlow) atomicAdd(&hist[min(mine, 255u)], 1u);
     __syncthreads();
     if (tid < 256) {
         const uint32_t nbin = hist[tid];
         if (nbin) atomicAdd(&ohist[tid], nbin);
     }
+}
+
+__global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __restrict__ entries,
+                                                             const uint32_t* __restrict__ seg_start, MsmShape sh,
+                                                             const uint32_t* __restrict__ counts,
+                                                             const uint32_t* __restrict__ offsets, uint32_t* sorted,
+                                                             const uint32_t* __restrict__ ohist, uint32_t* gcur, uint32_t* order) {
+    __shared__ uint32_t cur[256];    // running rank inside each bucket
+    __shared__ uint32_t pref[256];   // the bucket's start inside the segment
+    __shared__ uint32_t buf[256];    // scan of the size histogram
+    __shared__ uint32_t h[256];      // this segment's buckets per size bin
+    __shared__ uint32_t blk[256];    // where this segment's run inside each bin starts in order[]
+    const uint32_t s = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
+    const uint32_t start = seg_start[2 * s], end = seg_start[2 * s + 1];
+    const uint32_t nlow = 1u << sh.lb;
+    uint32_t key = 0, rank = 0, bucket = 0, v = 0;
+    const uint32_t k = 255 - tid;  // thread t scans size key 255 - t (descending order)
+    if (tid < 256) {
+        cur[tid] = 0;
+        h[tid] = 0;
+        v = ohist[k];
+        buf[tid] = v;
+        if (tid < nlow) {
+            bucket = s * nlow + tid;
+            pref[tid] = offsets[bucket] - start;
+            key = min(counts[bucket], 255u);
+        }
+    }
     __syncthreads();
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
+    if (tid < nlow) rank = atomicAdd(&h[key], 1u);
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t t = (tid < 256 && (int)tid >= off) ? buf[tid - off] : 0;
+        __syncthreads();
+        if (tid < 256) buf[tid] += t;
+        __syncthreads();
+    }
+    // claim this segment's run inside every occupied bin (the answer is needed only after the placement loop)
+    if (tid < 256) blk[k] = (buf[tid] - v) + (h[k] ? atomicAdd(&gcur[k], h[k]) : 0u);
+    const uint32_t low_sh = sh.ibits + sh.jbits + 1;
     for (uint32_t e = start + tid; e < end; e += nt) {
-        const uint32_t v = entries[e];
-        const uint32_t b = v >> low_sh;
-        const uint32_t r = atomicAdd(&hist[b], 1u);
-        const uint32_t i = v & ((1u << sh.ibits) - 1);
-        const uint32_t j = (v >> sh.ibits) & ((1u << sh.jbits) - 1);
-        const uint32_t neg = (v >> (sh.ibits + sh.jbits)) & 1u;
+        const uint32_t x = entries[e];
+        const uint32_t b = x >> low_sh;
+        const uint32_t r = atomicAdd(&cur[b], 1u);
+        const uint32_t i = x & ((1u << sh.ibits) - 1);
+        const uint32_t j = (x >> sh.ibits) & ((1u << sh.jbits) - 1);
+        const uint32_t neg = (x >> (sh.ibits + sh.jbits)) & 1u;
         sorted[start + pref[b] + r] = (j * sh.tlen + i) | (neg << 31);
     }
+    __syncthreads();
+    if (tid < nlow) order[blk[key] + rank] = bucket;
 }
 
 // ---- bucket schedule: order[] = bucket ids sorted by population, largest first --------------------
@@ -559,10 +710,64 @@ void launch_exclusive_scan(const uint32_t* in, uint64_t n, uint32_t* block_sums,
 
 uint32_t msm_segsort_blocks(uint64_t m) { return (uint32_t)((m + msm_chunk_for(m) - 1) / msm_chunk_for(m)); }
 
+// LDS of the staged scatter: three arrays of nseg words + the staging area; it is taken when that fits the 160 KiB of a CU
+// (table mode c = 20: 2048 scalars x 13 windows = 104 KiB + 24-48 KiB) and the fused row-prefix form applies
+static size_t msm_staged_lds(const MsmShape& sh) { return ((size_t)3 * sh.nseg + (size_t)sh.chunk * sh.W) * sizeof(uint32_t); }
+template <uint32_t C>
+static bool msm_staged_raise_lds() {
+    static int state[64] = {};   // per device ordinal: 0 = not tried, 1 = raised, -1 = refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] == 0)
+        state[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(msm_seg_scatter_staged_kernel<C>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : -1;
+    if (state[dev] < 0) (void)hipGetLastError();
+    return state[dev] > 0;
+}
+
+template <uint32_t C>
+static void launch_msm_segsort_c(const Fr* scalars, uint64_t m, const MsmShape& sh, uint32_t* blk_hist, uint32_t* blk_base,
+                                 uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries,
+                                 uint32_t* counts, uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514,
+                                 uint32_t* heavy, uint32_t* tasks, uint32_t* order, int staged_mode, hipStream_t s) {
+    const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
+    const uint32_t nt1 = msm_seg1_threads();
+    // the fused row-prefix form scans the segment totals in LDS next to the scatter's cursors (nseg + nt1 words); wider
+    // segment sets take the three-launch scan of the whole workgroup x segment matrix
+    const bool fused = sh.nseg <= 8192;
+    uint32_t* seg_tot = fused ? scan_scratch : nullptr;
+    const size_t lds_staged = msm_staged_lds(sh);
+    const bool staged = staged_mode != 0 && fused && blk_cnt && lds_staged <= 160 * 1024 &&
+                        (lds_staged <= 64 * 1024 || msm_staged_raise_lds<C>());
+    hipLaunchKernelGGL(msm_seg_hist_kernel<C>, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh, blk_hist,
+                       staged ? blk_cnt : (uint32_t*)nullptr);
+    if (fused)
+        hipLaunchKernelGGL(msm_seg_prefix_kernel, dim3(sh.nseg), dim3(256), 0, s, blk_hist, sh.nblk, blk_base, seg_tot, hist514,
+                           516u);
+    else
+        launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, 516u, s);
+    if (staged)
+        hipLaunchKernelGGL(msm_seg_scatter_staged_kernel<C>, dim3(sh.nblk), dim3(256), lds_staged, s, scalars, m, sh, blk_base, seg_tot,
+                           blk_cnt, entries);
+    else
+        hipLaunchKernelGGL(msm_seg_scatter_kernel<C>, dim3(sh.nblk), dim3(nt1), (fused ? sh.nseg + nt1 : sh.nseg) * sizeof(uint32_t),
+                           s, scalars, m, sh, blk_base, seg_tot, entries);
+    // long segments (short MSMs with few of them) get more threads per segment
+    const uint64_t seg_len = (uint64_t)sh.W * m / sh.nseg;
+    const uint32_t nt2 = seg_len >= 4096 ? 1024u : (seg_len >= 1536 ? 512u : 256u);
+    hipLaunchKernelGGL(msm_seg_count_kernel, dim3(sh.nseg), dim3(nt2), 0, s, entries, blk_base, seg_tot, sh, (uint32_t)nmat,
+                       counts, offsets, seg_start, cap, hist514, heavy, tasks);
+    hipLaunchKernelGGL(msm_seg_place_kernel, dim3(sh.nseg), dim3(nt2), 0, s, entries, seg_start, sh, counts, offsets, sorted,
+                       hist514, hist514 + 256, order);
+}
+
+// The whole bucket sort of one chunk of terms, bucket schedule (order[]) included.  staged_mode: 0 = the direct level-1
+// scatter everywhere (TYPLONK_MSM_SCATTER=direct, the A/B reference), else the LDS-staged one where it fits.
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
-                        uint32_t* scan_scratch, uint32_t* entries, uint32_t* counts, uint32_t* offsets, uint32_t* sorted,
-                        uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks, bool centred, hipStream_t s) {
+                        uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries, uint32_t* counts,
+                        uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks,
+                        uint32_t* order, bool centred, int staged_mode, hipStream_t s) {
     MsmShape sh;
     sh.centred = centred ? 1u : 0u;
     sh.c = c;
@@ -577,37 +782,23 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
     sh.nseg = (tlen ? nsets : W) << hb;
     sh.chunk = msm_chunk_for(m);
     sh.nblk = (uint32_t)((m + sh.chunk - 1) / sh.chunk);
-    const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
-    const uint32_t nt1 = msm_seg1_threads();
-    // the fused row-prefix form scans the segment totals in LDS next to the scatter's cursors (nseg + nt1 words); wider
-    // segment sets take the three-launch scan of the whole workgroup x segment matrix
-    const bool fused = sh.nseg <= 8192;
-    uint32_t* seg_tot = fused ? scan_scratch : nullptr;
-    hipLaunchKernelGGL(msm_seg_hist_kernel, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
-                       blk_hist);
-    if (fused)
-        hipLaunchKernelGGL(msm_seg_prefix_kernel, dim3(sh.nseg), dim3(256), 0, s, blk_hist, sh.nblk, blk_base, seg_tot, hist514,
-                           516u);
-    else
-        launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, 516u, s);
-    hipLaunchKernelGGL(msm_seg_scatter_kernel, dim3(sh.nblk), dim3(nt1), (fused ? sh.nseg + nt1 : sh.nseg) * sizeof(uint32_t),
-                       s, scalars, m, sh, blk_base, seg_tot, entries);
-    // long segments (short MSMs with few of them) get more threads per segment
-    const uint64_t seg_len = (uint64_t)sh.W * m / sh.nseg;
-    const uint32_t nt2 = seg_len >= 4096 ? 1024u : (seg_len >= 1536 ? 512u : 256u);
-    hipLaunchKernelGGL(msm_seg_sort_kernel, dim3(sh.nseg), dim3(nt2), 0, s, entries, blk_base, seg_tot, sh, (uint32_t)nmat,
-                       counts, offsets, sorted, cap, hist514, heavy, tasks);
+#define TY_SEGSORT(C) launch_msm_segsort_c<C>(scalars, m, sh, blk_hist, blk_base, scan_scratch, blk_cnt, seg_start, entries, counts, \
+                                              offsets, sorted, cap, hist514, heavy, tasks, order, staged_mode, s)
+    // the table windows get the constant-width digit extraction; every other width the run-time form
+    if (c == 20) TY_SEGSORT(20);
+    else if (c == 17) TY_SEGSORT(17);
+    else if (c == 15) TY_SEGSORT(15);
+    else TY_SEGSORT(0);
+#undef TY_SEGSORT
 }
 
+// bucket schedule after the ATOMIC counting sort (the segmented sort builds it itself, msm_seg_place_kernel)
 void launch_bucket_order(const uint32_t* counts, const uint32_t* offsets, uint32_t n, uint32_t cap, uint32_t* hist514,
-                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, bool hist_done, hipStream_t s) {
-    // hist514: histogram (256) + running bases (256) + heavy-bucket and task counters (2); hist_done: the segment sort
-    // has filled the histogram and the heavy-bucket lists already (launch_msm_segsort)
+                         uint32_t* order, uint32_t* heavy, uint32_t* tasks, hipStream_t s) {
+    // hist514: histogram (256) + running bases (256) + heavy-bucket and task counters (2)
     const uint32_t nblk = (n + 255) / 256;
-    if (!hist_done) {
-        (void)hipMemsetAsync(hist514, 0, 516 * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, offsets, n, cap, hist514, heavy, tasks);
-    }
+    (void)hipMemsetAsync(hist514, 0, 516 * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(order_hist_kernel, dim3(nblk), dim3(256), 0, s, counts, offsets, n, cap, hist514, heavy, tasks);
     hipLaunchKernelGGL(order_fused_kernel, dim3(nblk), dim3(256), 0, s, counts, n, hist514, hist514 + 256, order);
 }
 void launch_msm_scatter(const uint32_t* keys, uint64_t m, uint64_t total, uint32_t* cursor, uint32_t* sorted,

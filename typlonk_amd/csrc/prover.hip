@@ -436,8 +436,9 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     MsmQueue q(ctx, srs, /*first_lane=*/1);
     p->has_pi = pi_evals != nullptr;  // NULL: public inputs [0] -> the zero polynomial
     if (ctx->prover_ntt_batch) {
-        // the three interpolations (and the public-input column's, proof.rs:105-106) as ONE batched transform
-        // (ntt_run_batch), then the three commitments, then the coset extensions of the same group as one batch
+        // mode 1: the three interpolations (and the public-input column's, proof.rs:105-106) as ONE batched transform
+        // (ntt_run_batch), then the three commitments; mode 2: the first column alone -- its commitment starts at once --
+        // and the others as one batch beside it.  Either way the coset extensions of the group are one batch.
         for (int i = 0; i < 3 && !rc; ++i) {
             if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
             rc = d2d(p->co[i], wire_evals[i]->d);
@@ -445,8 +446,15 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
         if (!rc && p->has_pi) rc = d2d(p->pi, pi_evals->d);
         Fr* grp[4] = {p->co[0], p->co[1], p->co[2], p->pi};
         const size_t cnt = p->has_pi ? 4 : 3;
-        if (!rc) rc = ntt_run_batch(ctx, grp, cnt, log_n, 1, nullptr, false);
-        for (int i = 0; i < 3 && !rc; ++i) rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
+        if (ctx->prover_ntt_batch == 2) {
+            if (!rc) rc = ntt_run(ctx, p->co[0], log_n, 1, nullptr, false);
+            if (!rc) rc = q.submit(p->co[0], n, commit_xy[0], commit_inf);
+            if (!rc) rc = ntt_run_batch(ctx, grp + 1, cnt - 1, log_n, 1, nullptr, false);
+            for (int i = 1; i < 3 && !rc; ++i) rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
+        } else {
+            if (!rc) rc = ntt_run_batch(ctx, grp, cnt, log_n, 1, nullptr, false);
+            for (int i = 0; i < 3 && !rc; ++i) rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
+        }
         const int slots[4] = {0, 1, 2, 4};
         if (!rc) rc = prover_extend_batch(p, slots, grp, cnt);
     } else {
