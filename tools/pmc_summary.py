@@ -15,7 +15,8 @@ def per_kernel(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            # (templated kernels are listed as "void ty::name<20u>(...)")
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 

@@ -154,6 +154,9 @@ TY_HD uint32_t rc_weight(const RcShape& sh, uint32_t set, uint32_t kind, uint32_
     if (v <= sh.cl) return kind == 0 ? idx : (idx >> v) + 1;
     return kind == 0 ? (idx >> (v - sh.cl)) + 1 : 0u;
 }
+// first launch of the four-launch reduction: row partials (nrow threads, padded to nrow_pad) and column partials (ncol)
+void launch_msm_rc_partial(const uint32_t* buckets, const RcShape& sh, uint32_t nrow, uint32_t nrow_pad, uint32_t ncol, uint32_t* pb,
+                           uint32_t* pa, hipStream_t s);
 void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* pb, uint32_t* pa, uint32_t* sums,
                           uint32_t* bitsum, uint32_t* out, hipStream_t s);
 // the same bit planes in two launches (msm_reduce.hip); needs cl, ch >= 6; prow, pcol: nsets << (c1 - 6) points each

@@ -1,6 +1,7 @@
 // MSM staging kernels: infinity marking, scalar -> signed window digits + histogram, exclusive scan,
 // counting-sort scatter.  See msm_common.hpp for the overall MSM structure.
 #include "launch.hpp"
+#include <algorithm>
 #include "msm_common.hpp"
 
 namespace ty {
@@ -259,10 +260,20 @@ __device__ __forceinline__ void msm_for_each_digit_c(const uint32_t (&v)[8], con
     }
 }
 
-// canonical value of scalar i; centred != 0: min(k, r - k) instead, returns 1 when it is r - k (signs flip)
-__device__ __forceinline__ uint32_t msm_load_canon(const Fr* scalars, uint64_t i, uint32_t centred, uint32_t (&out)[8]) {
+// canonical value of a scalar from its two raw 16-byte halves; centred != 0: min(k, r - k) instead, returns 1 when it is
+// r - k (signs flip)
+struct MsmRawScalar {
+    uint4 a, b;
+};
+__device__ __forceinline__ MsmRawScalar msm_load_raw(const Fr* scalars, uint64_t i) {
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + i);
-    const uint4 a = sp[0], b = sp[1];
+    MsmRawScalar r;
+    r.a = sp[0];
+    r.b = sp[1];
+    return r;
+}
+__device__ __forceinline__ uint32_t msm_canon(const MsmRawScalar& raw, uint32_t centred, uint32_t (&out)[8]) {
+    const uint4 a = raw.a, b = raw.b;
     Fr s;
     s.v[0] = a.x; s.v[1] = a.y; s.v[2] = a.z; s.v[3] = a.w;
     s.v[4] = b.x; s.v[5] = b.y; s.v[6] = b.z; s.v[7] = b.w;
@@ -282,6 +293,28 @@ __device__ __forceinline__ uint32_t msm_load_canon(const Fr* scalars, uint64_t i
     for (int k = 0; k < 8; ++k) out[k] = s.v[k];
     return flip;
 }
+// The level-1 passes walk `per` scalars per thread (base + tid + nt * e).  One wavefront per SIMD is all the LDS staging
+// leaves room for, so nothing hides a load's latency but the thread's own work: the NEXT scalar is requested before the
+// current one's digits are cut.  body(i, canonical words, flip).
+template <class F>
+__device__ __forceinline__ void msm_walk_scalars(const Fr* scalars, uint64_t m, uint64_t base, uint32_t per, uint32_t centred, F&& body) {
+    const uint32_t nt = blockDim.x;
+    uint64_t i = base + threadIdx.x;
+    MsmRawScalar cur{};
+    if (per && i < m) cur = msm_load_raw(scalars, i);
+    for (uint32_t e = 0; e < per; ++e) {
+        const uint64_t nxt = i + nt;
+        MsmRawScalar ahead{};
+        if (e + 1 < per && nxt < m) ahead = msm_load_raw(scalars, nxt);
+        if (i < m) {
+            uint32_t v[8];
+            const uint32_t flip = msm_canon(cur, centred, v);
+            body((uint32_t)i, v, flip);
+        }
+        cur = ahead;
+        i = nxt;
+    }
+}
 
 // blk_cnt != nullptr: also the workgroup's own row of counts, contiguous (the staged scatter scans it for its LDS layout)
 template <uint32_t C>
@@ -291,17 +324,12 @@ __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, u
     const uint32_t nt = blockDim.x;
     for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) seg_h[s] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
-    for (uint32_t e = 0; e < sh.chunk / nt; ++e) {
-        const uint64_t i = base + threadIdx.x + nt * e;
-        if (i < m) {
-            uint32_t v[8];
-            (void)msm_load_canon(scalars, i, sh.centred, v);
-            msm_for_each_digit_c<C>(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t) {
-                atomicAdd(&seg_h[msm_seg_of(sh, j, b)], 1u);
-            });
-        }
-    }
+    msm_walk_scalars(scalars, m, (uint64_t)blockIdx.x * sh.chunk, sh.chunk / nt, sh.centred,
+                     [&](uint32_t i, const uint32_t (&v)[8], uint32_t) {
+                         msm_for_each_digit_c<C>(v, sh, i, [&](uint32_t j, uint32_t b, uint32_t) {
+                             atomicAdd(&seg_h[msm_seg_of(sh, j, b)], 1u);
+                         });
+                     });
     __syncthreads();
     const uint32_t col = msm_seg_col(sh, blockIdx.x);
     for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) {
@@ -369,39 +397,72 @@ __device__ __forceinline__ void msm_seg_starts(const uint32_t* __restrict__ seg_
     __syncthreads();
 }
 
+// two exclusive scans of nseg words each in one pass (sa[] of a[], sb[] of b[]); scratch: 2 * blockDim.x words
+__device__ __forceinline__ void msm_seg_starts2(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t nseg,
+                                                uint32_t* sa, uint32_t* sb, uint32_t* scratch) {
+    const uint32_t nt = blockDim.x, per = (nseg + nt - 1) / nt;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nseg);
+    uint32_t suma = 0, sumb = 0;
+    for (uint32_t s = lo; s < hi; ++s) {
+        suma += a[s];
+        sumb += b[s];
+    }
+    scratch[threadIdx.x] = suma;
+    scratch[nt + threadIdx.x] = sumb;
+    __syncthreads();
+    for (uint32_t off = 1; off < nt; off <<= 1) {
+        const uint32_t ta = threadIdx.x >= off ? scratch[threadIdx.x - off] : 0;
+        const uint32_t tb = threadIdx.x >= off ? scratch[nt + threadIdx.x - off] : 0;
+        __syncthreads();
+        scratch[threadIdx.x] += ta;
+        scratch[nt + threadIdx.x] += tb;
+        __syncthreads();
+    }
+    uint32_t runa = scratch[threadIdx.x] - suma, runb = scratch[nt + threadIdx.x] - sumb;
+    __syncthreads();   // (scratch may be the caller's output area)
+    for (uint32_t s = lo; s < hi; ++s) {
+        sa[s] = runa;
+        sb[s] = runb;
+        runa += a[s];
+        runb += b[s];
+    }
+    __syncthreads();
+}
+
 // seg_tot == nullptr: blk_base holds absolute positions (the three-launch scan); else row prefixes + segment totals
 // (the direct form: every entry goes straight to its place in global memory, 4 bytes at a time.  Kept for the shapes whose
 // staging area does not fit the LDS; the staged form below is the one the table-mode MSMs take)
 template <uint32_t C>
 __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
                                                                const uint32_t* blk_base, const uint32_t* seg_tot,
-                                                               uint32_t* entries) {
+                                                               uint32_t* seg_start, uint32_t* entries) {
     extern __shared__ uint32_t seg_sm[];
     uint32_t* cur = seg_sm;             // running position of this workgroup inside each segment
     const uint32_t nt = blockDim.x;
     const uint32_t col = msm_seg_col(sh, blockIdx.x);
     if (seg_tot) {
         msm_seg_starts(seg_tot, sh.nseg, cur, seg_sm + sh.nseg);
+        if (blockIdx.x == 0)   // level 2 reads every segment's range from here instead of summing the totals again
+            for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) {
+                seg_start[2 * s] = cur[s];
+                seg_start[2 * s + 1] = cur[s] + seg_tot[s];
+            }
+        __syncthreads();
         for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] += blk_base[(uint64_t)s * sh.nblk + col];
     } else {
         for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) cur[s] = blk_base[(uint64_t)s * sh.nblk + col];
     }
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
     const uint32_t lmask = (1u << sh.lb) - 1;
-    for (uint32_t e = 0; e < sh.chunk / nt; ++e) {
-        const uint64_t i = base + threadIdx.x + nt * e;
-        if (i < m) {
-            uint32_t v[8];
-            const uint32_t flip = msm_load_canon(scalars, i, sh.centred, v);
-            msm_for_each_digit_c<C>(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
-                const uint32_t pos = atomicAdd(&cur[msm_seg_of(sh, j, b)], 1u);
-                neg ^= flip;
-                entries[pos] = (uint32_t)i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
-                               ((b & lmask) << (sh.ibits + sh.jbits + 1));
-            });
-        }
-    }
+    msm_walk_scalars(scalars, m, (uint64_t)blockIdx.x * sh.chunk, sh.chunk / nt, sh.centred,
+                     [&](uint32_t i, const uint32_t (&v)[8], uint32_t flip) {
+                         msm_for_each_digit_c<C>(v, sh, i, [&](uint32_t j, uint32_t b, uint32_t neg) {
+                             const uint32_t pos = atomicAdd(&cur[msm_seg_of(sh, j, b)], 1u);
+                             neg ^= flip;
+                             entries[pos] = i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
+                                            ((b & lmask) << (sh.ibits + sh.jbits + 1));
+                         });
+                     });
 }
 
 // The staged form (round 6).  The direct form above writes 4 bytes wherever an entry belongs: W entries per scalar into
@@ -416,7 +477,8 @@ template <uint32_t C>
 __global__ __launch_bounds__(256) void msm_seg_scatter_staged_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
                                                                      const uint32_t* __restrict__ blk_base,
                                                                      const uint32_t* __restrict__ seg_tot,
-                                                                     const uint32_t* __restrict__ blk_cnt, uint32_t* entries) {
+                                                                     const uint32_t* __restrict__ blk_cnt, uint32_t* seg_start,
+                                                                     uint32_t* entries) {
     extern __shared__ uint32_t seg_sm[];
     uint32_t* rank = seg_sm;
     uint32_t* loc = seg_sm + sh.nseg;
@@ -424,37 +486,47 @@ __global__ __launch_bounds__(256) void msm_seg_scatter_staged_kernel(const Fr* s
     uint32_t* stage = seg_sm + 3 * sh.nseg;
     const uint32_t nt = blockDim.x, tid = threadIdx.x;
     const uint32_t col = msm_seg_col(sh, blockIdx.x);
-    // global start of this workgroup's run in every segment; local start of every segment in the staging area
-    // (the staging area doubles as the scans' scratch: nothing is staged yet)
-    msm_seg_starts(seg_tot, sh.nseg, gst, stage);
-    msm_seg_starts(blk_cnt + (uint64_t)blockIdx.x * sh.nseg, sh.nseg, loc, stage);
+    // global start of every segment (exclusive scan of the segment totals) and local start of every segment in the staging
+    // area (exclusive scan of this workgroup's own counts), both in ONE pass; the staging area doubles as the scans' scratch
+    msm_seg_starts2(seg_tot, blk_cnt + (uint64_t)blockIdx.x * sh.nseg, sh.nseg, gst, loc, stage);
+    if (blockIdx.x == 0)   // level 2 reads every segment's range from here instead of summing the totals again
+        for (uint32_t s = tid; s < sh.nseg; s += nt) {
+            seg_start[2 * s] = gst[s];
+            seg_start[2 * s + 1] = gst[s] + seg_tot[s];
+        }
+    __syncthreads();
     for (uint32_t s = tid; s < sh.nseg; s += nt) {
         gst[s] += blk_base[(uint64_t)s * sh.nblk + col];
         rank[s] = 0;
     }
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * sh.chunk;
     const uint32_t lmask = (1u << sh.lb) - 1;
-    for (uint32_t e = 0; e < sh.chunk / nt; ++e) {
-        const uint64_t i = base + tid + nt * e;
-        if (i < m) {
-            uint32_t v[8];
-            const uint32_t flip = msm_load_canon(scalars, i, sh.centred, v);
-            msm_for_each_digit_c<C>(v, sh, (uint32_t)i, [&](uint32_t j, uint32_t b, uint32_t neg) {
-                const uint32_t sg = msm_seg_of(sh, j, b);
-                const uint32_t r = atomicAdd(&rank[sg], 1u);
-                neg ^= flip;
-                stage[loc[sg] + r] = (uint32_t)i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
-                                     ((b & lmask) << (sh.ibits + sh.jbits + 1));
-            });
-        }
-    }
+    msm_walk_scalars(scalars, m, (uint64_t)blockIdx.x * sh.chunk, sh.chunk / nt, sh.centred,
+                     [&](uint32_t i, const uint32_t (&v)[8], uint32_t flip) {
+                         msm_for_each_digit_c<C>(v, sh, i, [&](uint32_t j, uint32_t b, uint32_t neg) {
+                             const uint32_t sg = msm_seg_of(sh, j, b);
+                             const uint32_t r = atomicAdd(&rank[sg], 1u);
+                             neg ^= flip;
+                             stage[loc[sg] + r] = i | ((sh.jbits ? j : 0u) << sh.ibits) | (neg << (sh.ibits + sh.jbits)) |
+                                                  ((b & lmask) << (sh.ibits + sh.jbits + 1));
+                         });
+                     });
     __syncthreads();
-    // copy-out: quarter wavefront q takes segments q, q + nt/16, ...; rank[] now holds the run lengths
+    // copy-out: a quarter wavefront (16 lanes) per run, four runs in flight per quarter (their LDS look-ups are issued
+    // together); rank[] now holds the run lengths
     const uint32_t q = tid >> 4, l = tid & 15u, nq = nt >> 4;
-    for (uint32_t sg = q; sg < sh.nseg; sg += nq) {
-        const uint32_t len = rank[sg], src = loc[sg], dst = gst[sg];
-        for (uint32_t k = l; k < len; k += 16) entries[dst + k] = stage[src + k];
+    for (uint32_t sg0 = 4 * q; sg0 < sh.nseg; sg0 += 4 * nq) {
+        uint32_t len[4], src[4], dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t sg = min(sg0 + u, sh.nseg - 1);
+            len[u] = sg0 + u < sh.nseg ? rank[sg] : 0u;
+            src[u] = loc[sg];
+            dst[u] = gst[sg];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            for (uint32_t k = l; k < len[u]; k += 16) entries[dst[u] + k] = stage[src[u] + k];
     }
 }
 
@@ -469,6 +541,24 @@ __global__ __launch_bounds__(256) void msm_seg_scatter_staged_kernel(const Fr* s
 //                         256-bin histogram for itself and claims its run inside each bin from a global cursor).  The claim's
 //                         round trip to the L2 hides under the placement loop.
 // 256, 512 or 1024 threads: all of them walk the segment, the first 256 own the 2^lb <= 256 buckets.
+// inclusive scan over the values of threads 0..255 (four wavefronts): shuffles inside a wavefront, one LDS hand-over
+// between them -- two barriers where the Hillis-Steele form over LDS takes sixteen.  Every thread of the workgroup calls it.
+__device__ __forceinline__ uint32_t msm_scan256_incl(uint32_t v, uint32_t* wsum /* 4 words of LDS */) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(x, off);
+        if ((int)lane >= off) x += t;
+    }
+    if (tid < 256 && lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (tid < 256)
+        for (uint32_t w = 0; w < wave; ++w) x += wsum[w];
+    __syncthreads();
+    return x;
+}
+
 __global__ __launch_bounds__(1024) void msm_seg_count_kernel(const uint32_t* __restrict__ entries,
                                                              const uint32_t* __restrict__ blk_base,
                                                              const uint32_t* __restrict__ seg_tot, MsmShape sh,
@@ -476,28 +566,19 @@ __global__ __launch_bounds__(1024) void msm_seg_count_kernel(const uint32_t* __r
                                                              uint32_t* seg_start, uint32_t cap, uint32_t* ohist, uint32_t* heavy,
                                                              uint32_t* tasks) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t pref[256];
-    __shared__ uint32_t red[1024];
+    __shared__ uint32_t wsum[4];
     const uint32_t s = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
     uint32_t start, end;
-    if (seg_tot) {  // segment start = sum of the totals before it
-        uint32_t sum = 0;
-        for (uint32_t i = tid; i < s; i += nt) sum += seg_tot[i];
-        red[tid] = sum;
-        __syncthreads();
-        for (uint32_t off = nt >> 1; off > 0; off >>= 1) {
-            if (tid < off) red[tid] += red[tid + off];
-            __syncthreads();
-        }
-        start = red[0];
-        end = start + seg_tot[s];
+    if (seg_tot) {  // the fused row-prefix form: the level-1 scatter has published every segment's range
+        start = seg_start[2 * s];
+        end = seg_start[2 * s + 1];
     } else {
         start = blk_base[(uint64_t)s * sh.nblk];
         end = (s + 1 < sh.nseg) ? blk_base[(uint64_t)(s + 1) * sh.nblk] : blk_base[total_slot];
-    }
-    if (tid == 0) {
-        seg_start[2 * s] = start;
-        seg_start[2 * s + 1] = end;
+        if (tid == 0) {
+            seg_start[2 * s] = start;
+            seg_start[2 * s + 1] = end;
+        }
     }
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
@@ -505,16 +586,7 @@ __global__ __launch_bounds__(1024) void msm_seg_count_kernel(const uint32_t* __r
     for (uint32_t e = start + tid; e < end; e += nt) atomicAdd(&hist[entries[e] >> low_sh], 1u);
     __syncthreads();
     const uint32_t mine = tid < 256 ? hist[tid] : 0;
-    if (tid < 256) pref[tid] = mine;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t t = (tid < 256 && (int)tid >= off) ? pref[tid - off] : 0;
-        __syncthreads();
-        if (tid < 256) pref[tid] += t;
-        __syncthreads();
-    }
-    const uint32_t excl = tid < 256 ? pref[tid] - mine : 0;
-    __syncthreads();
+    const uint32_t excl = msm_scan256_incl(mine, wsum) - mine;
     if (tid < 256) hist[tid] = 0;
     const uint32_t nlow = 1u << sh.lb;
     if (tid < nlow) {
@@ -558,7 +630,7 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
                                                              const uint32_t* __restrict__ ohist, uint32_t* gcur, uint32_t* order) {
     __shared__ uint32_t cur[256];    // running rank inside each bucket
     __shared__ uint32_t pref[256];   // the bucket's start inside the segment
-    __shared__ uint32_t buf[256];    // scan of the size histogram
+    __shared__ uint32_t wsum[4];
     __shared__ uint32_t h[256];      // this segment's buckets per size bin
     __shared__ uint32_t blk[256];    // where this segment's run inside each bin starts in order[]
     const uint32_t s = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
@@ -570,7 +642,6 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
         cur[tid] = 0;
         h[tid] = 0;
         v = ohist[k];
-        buf[tid] = v;
         if (tid < nlow) {
             bucket = s * nlow + tid;
             pref[tid] = offsets[bucket] - start;
@@ -579,14 +650,9 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
     }
     __syncthreads();
     if (tid < nlow) rank = atomicAdd(&h[key], 1u);
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t t = (tid < 256 && (int)tid >= off) ? buf[tid - off] : 0;
-        __syncthreads();
-        if (tid < 256) buf[tid] += t;
-        __syncthreads();
-    }
+    const uint32_t larger = msm_scan256_incl(v, wsum) - v;   // buckets with a larger size key (the scan has two barriers: h[] is complete)
     // claim this segment's run inside every occupied bin (the answer is needed only after the placement loop)
-    if (tid < 256) blk[k] = (buf[tid] - v) + (h[k] ? atomicAdd(&gcur[k], h[k]) : 0u);
+    if (tid < 256) blk[k] = larger + (h[k] ? atomicAdd(&gcur[k], h[k]) : 0u);
     const uint32_t low_sh = sh.ibits + sh.jbits + 1;
     for (uint32_t e = start + tid; e < end; e += nt) {
         const uint32_t x = entries[e];
@@ -712,7 +778,9 @@ uint32_t msm_segsort_blocks(uint64_t m) { return (uint32_t)((m + msm_chunk_for(m
 
 // LDS of the staged scatter: three arrays of nseg words + the staging area; it is taken when that fits the 160 KiB of a CU
 // (table mode c = 20: 2048 scalars x 13 windows = 104 KiB + 24-48 KiB) and the fused row-prefix form applies
-static size_t msm_staged_lds(const MsmShape& sh) { return ((size_t)3 * sh.nseg + (size_t)sh.chunk * sh.W) * sizeof(uint32_t); }
+static size_t msm_staged_lds(const MsmShape& sh) {
+    return ((size_t)3 * sh.nseg + std::max<size_t>((size_t)sh.chunk * sh.W, 512)) * sizeof(uint32_t);   // (>= the scans' scratch)
+}
 template <uint32_t C>
 static bool msm_staged_raise_lds() {
     static int state[64] = {};   // per device ordinal: 0 = not tried, 1 = raised, -1 = refused
@@ -748,10 +816,10 @@ static void launch_msm_segsort_c(const Fr* scalars, uint64_t m, const MsmShape& 
         launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, 516u, s);
     if (staged)
         hipLaunchKernelGGL(msm_seg_scatter_staged_kernel<C>, dim3(sh.nblk), dim3(256), lds_staged, s, scalars, m, sh, blk_base, seg_tot,
-                           blk_cnt, entries);
+                           blk_cnt, seg_start, entries);
     else
         hipLaunchKernelGGL(msm_seg_scatter_kernel<C>, dim3(sh.nblk), dim3(nt1), (fused ? sh.nseg + nt1 : sh.nseg) * sizeof(uint32_t),
-                           s, scalars, m, sh, blk_base, seg_tot, entries);
+                           s, scalars, m, sh, blk_base, seg_tot, seg_start, entries);
     // long segments (short MSMs with few of them) get more threads per segment
     const uint64_t seg_len = (uint64_t)sh.W * m / sh.nseg;
     const uint32_t nt2 = seg_len >= 4096 ? 1024u : (seg_len >= 1536 ? 512u : 256u);
