@@ -7,7 +7,7 @@
 //! Seams (file:line under the reference):
 //!   * `Backend::msm`            replaces the body of `KzgScheme::evaluate_in_s`      kzg/src/lib.rs:41-54
 //!   * `Backend::upload_srs`     once per `Srs` (`Srs::from_secret`)                  kzg/src/srs.rs:30-34
-//!   * `Backend::interpolate` / `evaluate_over_domain`
+//!   * `Backend::interpolate` / `interpolate_batch` / `evaluate_over_domain`
 //!                               replace `Evaluations::interpolate()` / `evaluate_over_domain()`
 //!                               plonk/src/proof.rs:50,106,115,125,128  plonk/src/builder.rs:85
 //!   * `Backend::load_circuit` + `Backend::prove`
@@ -147,6 +147,16 @@ impl Backend {
         h
     }
 
+    /// `typlonk_srs_free`: the device copy of an SRS and its fixed-base tables (13-17 x the SRS when built).  Called by
+    /// `OwnedSrs::drop`; a handle must not be used afterwards.
+    pub fn free_srs(&self, srs: SrsHandle) {
+        self.check(unsafe { ffi::typlonk_srs_free(self.ctx, srs.id) });
+    }
+    /// `typlonk_circuit_free`: the per-circuit coset evaluations (9 x 4n + 11 x n Fr).  Called by `OwnedCircuit::drop`.
+    pub fn free_circuit(&self, circuit: CircuitHandle) {
+        self.check(unsafe { ffi::typlonk_circuit_free(self.ctx, circuit.id) });
+    }
+
     /// `typlonk_srs_precompute`: speed only, results unchanged; the window is chosen by length (nothing at all below
     /// TYPLONK_TABLES_AUTO_MIN_LEN points).  13-17 copies of the SRS in HBM.
     pub fn precompute_tables(&self, srs: SrsHandle) {
@@ -198,6 +208,36 @@ impl Backend {
             *e = fr_from_limbs([l[0], l[1], l[2], l[3]]);
         }
         Poly::from_coefficients_vec(evals)
+    }
+
+    /// A GROUP of interpolations in one call -- the three wire columns (plonk/src/proof.rs:50), the three sigma columns
+    /// (:334-338), the five selector columns (plonk/src/builder.rs:84-88): one upload, ONE `typlonk_ntt_fr_batch_devptr`
+    /// (every pass of the transform is a single launch carrying all the columns), one download; each result gets ark-poly's
+    /// trailing-zero trim like `interpolate`.
+    pub fn interpolate_batch(&self, columns: Vec<Vec<Fr>>, log_n: u32) -> Vec<Poly> {
+        let n = 1usize << log_n;
+        let count = columns.len();
+        if count == 0 {
+            return Vec::new();
+        }
+        let mut limbs: Vec<u64> = Vec::with_capacity(4 * n * count);
+        for col in &columns {
+            assert_eq!(col.len(), n);
+            limbs.extend(col.iter().flat_map(|e| fr_limbs(e)));
+        }
+        let mut buf = ptr::null_mut();
+        self.check(unsafe { ffi::typlonk_buf_alloc(self.ctx, n * count, &mut buf) });
+        let dev = DeviceVec { backend: self, buf }; // freed on drop, also when a check below panics
+        self.check(unsafe { ffi::typlonk_buf_upload(self.ctx, dev.buf, 0, limbs.as_ptr(), n * count) });
+        let base = unsafe { ffi::typlonk_buf_devptr(dev.buf) } as *mut u8;
+        let ptrs: Vec<*mut std::os::raw::c_void> =
+            (0..count).map(|v| unsafe { base.add(32 * n * v) } as *mut std::os::raw::c_void).collect();
+        self.check(unsafe { ffi::typlonk_ntt_fr_batch_devptr(self.ctx, ptrs.as_ptr(), count, log_n, 1, ptr::null()) });
+        self.check(unsafe { ffi::typlonk_buf_download(self.ctx, dev.buf, 0, limbs.as_mut_ptr(), n * count) });
+        limbs
+            .chunks_exact(4 * n)
+            .map(|col| Poly::from_coefficients_vec(col.chunks_exact(4).map(|l| fr_from_limbs([l[0], l[1], l[2], l[3]])).collect()))
+            .collect()
     }
 
     /// `poly.evaluate_over_domain(domain).evals`: zero-pad to the domain size, fft, natural order
@@ -304,6 +344,53 @@ impl From<&ffi::TyplonkProof> for ProofParts {
             evals: [0, 1, 2, 3, 4, 5].map(|i| fr_from_limbs(p.tail.evals[i])),
             evaluation_point: fr_from_limbs(p.zeta),
         }
+    }
+}
+
+/// An SRS resident on the shared context of its thread, freed when dropped: what the patched `kzg::srs::Srs` holds.
+/// (`Backend::shared` keeps ONE context per thread and device alive for the thread's lifetime, so the device memory of
+/// an `Srs` must be returned when the `Srs` goes -- not when the context does.)
+#[derive(Debug)]
+pub struct OwnedSrs {
+    backend: std::rc::Rc<Backend>,
+    handle: SrsHandle,
+}
+impl OwnedSrs {
+    pub fn new(backend: std::rc::Rc<Backend>, handle: SrsHandle) -> Self {
+        OwnedSrs { backend, handle }
+    }
+    pub fn backend(&self) -> &Backend {
+        &self.backend
+    }
+    pub fn backend_rc(&self) -> std::rc::Rc<Backend> {
+        self.backend.clone()
+    }
+    pub fn handle(&self) -> SrsHandle {
+        self.handle
+    }
+}
+impl Drop for OwnedSrs {
+    fn drop(&mut self) {
+        unsafe { ffi::typlonk_srs_free(self.backend.ctx, self.handle.id) }; // (no panic in drop: the status is ignored)
+    }
+}
+/// The per-circuit device constants (`typlonk_circuit_load`), freed when dropped: what the patched `CompiledCircuit` holds.
+#[derive(Debug)]
+pub struct OwnedCircuit {
+    backend: std::rc::Rc<Backend>,
+    handle: CircuitHandle,
+}
+impl OwnedCircuit {
+    pub fn new(backend: std::rc::Rc<Backend>, handle: CircuitHandle) -> Self {
+        OwnedCircuit { backend, handle }
+    }
+    pub fn handle(&self) -> CircuitHandle {
+        self.handle
+    }
+}
+impl Drop for OwnedCircuit {
+    fn drop(&mut self) {
+        unsafe { ffi::typlonk_circuit_free(self.backend.ctx, self.handle.id) };
     }
 }
 

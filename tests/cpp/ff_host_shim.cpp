@@ -39,18 +39,6 @@ void shim_fr_to_mont(const uint32_t* a, uint32_t* o) { st(o, fe_to_mont(ld<Fr>(a
 // Fq30: la / lb = number of extra multiples of p added to the operands before the operation
 void shim_fq_roundtrip(const uint32_t* a, uint32_t* o) { stq(o, ldq(a)); }
 void shim_fq_mul(const uint32_t* a, const uint32_t* b, int la, int lb, uint32_t* o) { stq(o, fq30_mul(lift(ldq(a), la), lift(ldq(b), lb))); }
-// the column-parallel forms (fq30_mul_ilp & co, the bucket reduction's chains): must give the same digits
-void shim_fq_mul_ilp(const uint32_t* a, const uint32_t* b, int la, int lb, uint32_t* o) { stq(o, fq30_mul_ilp(lift(ldq(a), la), lift(ldq(b), lb))); }
-void shim_fq_sqr_ilp(const uint32_t* a, int la, uint32_t* o) { stq(o, fq30_sqr_ilp(lift(ldq(a), la))); }
-// 1 if fq30_mul_ilp / fq30_sqr_ilp / fq30_mul2_add_ilp give limb for limb what the single-accumulator forms give
-int shim_fq_ilp_agree(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, int la, int lb) {
-    const Fq30 x = lift(ldq(a), la), y = lift(ldq(b), lb), z = ldq(c), w = ldq(d);
-    int ok = 1;
-    const Fq30 m0 = fq30_mul_fused(x, y), m1 = fq30_mul_ilp(x, y), s0 = fq30_sqr_fused(x), s1 = fq30_sqr_ilp(x);
-    const Fq30 t0 = fq30_mul2_add(x, z, y, w), t1 = fq30_mul2_add_ilp(x, z, y, w);
-    for (int i = 0; i < 13; ++i) ok &= (m0.v[i] == m1.v[i]) & (s0.v[i] == s1.v[i]) & (t0.v[i] == t1.v[i]);
-    return ok;
-}
 void shim_fq_sqr(const uint32_t* a, int la, uint32_t* o) { stq(o, fq30_sqr(lift(ldq(a), la))); }
 void shim_fq_add(const uint32_t* a, const uint32_t* b, int la, int lb, uint32_t* o) { stq(o, fq30_add_lazy(lift(ldq(a), la), lift(ldq(b), lb))); }
 void shim_fq_sub(const uint32_t* a, const uint32_t* b, int la, int lb, uint32_t* o) {  // b + lb*p <= 6p

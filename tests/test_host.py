@@ -87,9 +87,6 @@ def test_fq30_arithmetic_vs_bigint(shim):
         assert _q(shim, "shim_fq_roundtrip", _fq(a)) == a
         assert _q(shim, "shim_fq_mul", _fq(a), _fq(b), la, lb) == a * b % O.P
         assert _q(shim, "shim_fq_sqr", _fq(a), la) == a * a % O.P
-        assert _q(shim, "shim_fq_mul_ilp", _fq(a), _fq(b), la, lb) == a * b % O.P      # column-parallel forms (fq30_mul_ilp):
-        assert _q(shim, "shim_fq_sqr_ilp", _fq(a), la) == a * a % O.P                   # same values ...
-        assert shim.shim_fq_ilp_agree(u32p(_fq(a)), u32p(_fq(b)), u32p(_fq(c)), u32p(_fq((a ^ c) % O.P)), la % 5, lb % 4) == 1   # ... same limbs
         assert _q(shim, "shim_fq_add", _fq(a), _fq(b), la % 4, lb % 4) == (a + b) % O.P
         assert _q(shim, "shim_fq_sub", _fq(a), _fq(b), la, lb % 6) == (a - b) % O.P
         assert _q(shim, "shim_fq_sub2", _fq(a), _fq(b), _fq(c)) == (a - b - c) % O.P

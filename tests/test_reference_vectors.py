@@ -136,6 +136,9 @@ def test_radix2_domain_transforms(vec):
     coeffs = [_fr(c) for c in vec["msm8"]["coeffs"]]
     assert [_fr(x) for x in f["fft8_of_msm8_coeffs"]] == O.ntt(coeffs, 3)
     assert [_fr(x) for x in f["coset_fft8_of_msm8_coeffs"]] == O.ntt(coeffs, 3, coset=7)
+    if "interpolate3" in vec:    # a group of Evaluations::interpolate calls (proof.rs:50): the oracle's inverse NTT, column by column
+        for col, poly in zip(vec["interpolate3"]["columns"], vec["interpolate3"]["polys"]):
+            assert [_fr(x) for x in poly] == O.ntt([_fr(x) for x in col], 3, inverse=True)
 
 
 @pytest.mark.gpu
@@ -160,3 +163,9 @@ def test_hip_path_on_the_reference_vectors(vec, ctx):
     assert (ctx.ntt(data, 3) == np.array([_limbs(x) for x in f["fft8_of_msm8_coeffs"]], dtype=np.uint64)).all()
     seven = np.array(O.fr_to_mont_limbs(7), dtype=np.uint64)
     assert (ctx.ntt(data, 3, coset=seven) == np.array([_limbs(x) for x in f["coset_fft8_of_msm8_coeffs"]], dtype=np.uint64)).all()
+    if "interpolate3" in vec:    # the group through ONE typlonk_ntt_fr_batch_devptr call
+        it = vec["interpolate3"]
+        buf = ctx.alloc(24)
+        buf.upload(np.array([_limbs(x) for c in it["columns"] for x in c], dtype=np.uint64))
+        ctx.ntt_batch_devptr([buf.devptr + 32 * 8 * v for v in range(3)], 3, inverse=True)
+        assert (buf.download() == np.array([_limbs(x) for c in it["polys"] for x in c], dtype=np.uint64)).all()

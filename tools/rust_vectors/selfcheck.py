@@ -45,6 +45,8 @@ v = [1, 2, 3, 4]
 out["fft"] = {"input": [fr(x) for x in v], "fft4": [fr(x) for x in O.ntt(v, 2)], "ifft4": [fr(x) for x in O.ntt(v, 2, inverse=True)],
               "fft8_of_msm8_coeffs": [fr(x) for x in O.ntt(coeffs, 3)], "coset_fft8_of_msm8_coeffs": [fr(x) for x in O.ntt(coeffs, 3, coset=7)],
               "group_gen_8": fr(O.domain_root(3))}
+cols = [[O.fr_from_mont_limbs([int(v) for v in T.fr_rand(rng)]) for _ in range(8)] for _ in range(3)]   # drawn after the msm8 coefficients
+out["interpolate3"] = {"columns": [[fr(x) for x in c] for c in cols], "polys": [[fr(x) for x in O.ntt(c, 3, inverse=True)] for c in cols]}
 with tempfile.TemporaryDirectory() as d:
     path = os.path.join(d, "reference_vectors.json")
     json.dump(out, open(path, "w"))

@@ -10,6 +10,8 @@
 //!   commit / open            kzg/src/lib.rs:37-64, the crate's own test polynomial 1 + 2X + 3X^2 under s = 2 (:95-109)
 //!   srs                      kzg/src/srs.rs:15-34
 //!   fft / ifft               ark-poly Radix2EvaluationDomain as reached from plonk/src/proof.rs:50, 115
+//!   interpolate3             a group of three `Evaluations::interpolate` calls (plonk/src/proof.rs:50, builder.rs:84-88):
+//!                            what one typlonk_ntt_fr_batch_devptr(inverse) call must return
 //!   msm8                     evaluate_in_s on an 8-term polynomial with a large secret
 //!   srs_slice                kzg/src/srs.rs:15-24 at a NON-ZERO start: powers 30..36 of the large secret (what
 //!                            typlonk_srs_generate(start = 30) must reproduce -- fixed-base comb + divsteps inversion)
@@ -164,6 +166,25 @@ fn emit_reference_vectors() {
     let dom8 = GeneralEvaluationDomain::<Fr>::new(8).unwrap();
     let f8 = dom8.fft(&coeffs);
     let c8f = dom8.coset_fft(&coeffs); // coset generator Fr::multiplicative_generator() = 7
+    // a GROUP of interpolations, as the reference issues them (the three wire columns, plonk/src/proof.rs:50; the five
+    // selector columns, plonk/src/builder.rs:84-88): three columns of eight values drawn after the msm8 coefficients from
+    // the same generator, each through Evaluations::interpolate -- what ONE typlonk_ntt_fr_batch_devptr(inverse) call returns
+    let cols: Vec<Vec<Fr>> = (0..3).map(|_| (0..8).map(|_| Fr::rand(&mut rng)).collect()).collect();
+    let polys: Vec<Vec<Fr>> = cols
+        .iter()
+        .map(|c| {
+            let mut co = ark_poly::Evaluations::from_vec_and_domain(c.clone(), dom8).interpolate().coeffs;
+            co.resize(8, Fr::zero()); // ark-poly trims trailing zeros
+            co
+        })
+        .collect();
+    writeln!(
+        out,
+        "\"interpolate3\": {{\"columns\":{},\"polys\":{}}},",
+        list(cols.iter().map(|c| list(c.iter().map(fr_json).collect())).collect()),
+        list(polys.iter().map(|c| list(c.iter().map(fr_json).collect())).collect())
+    )
+    .unwrap();
     writeln!(
         out,
         "\"fft\": {{\"input\":{},\"fft4\":{},\"ifft4\":{},\"fft8_of_msm8_coeffs\":{},\"coset_fft8_of_msm8_coeffs\":{},\"group_gen_8\":{}}}",

@@ -37,7 +37,7 @@ def hipcc_path() -> str:
     return p
 
 
-HIP_UNITS = ["ctx.hip", "ntt_host.hip", "msm_host.hip", "comm.hip", "prover.hip", "ntt_kernels.hip", "msm_sort.hip", "msm_accum.hip", "msm_reduce.hip", "msm_rc_partial.hip", "srs_gen.hip", "quotient.hip", "plonk_ops.hip"]
+HIP_UNITS = ["ctx.hip", "ntt_host.hip", "msm_host.hip", "comm.hip", "prover.hip", "ntt_kernels.hip", "msm_sort.hip", "msm_accum.hip", "msm_reduce.hip", "srs_gen.hip", "quotient.hip", "plonk_ops.hip"]
 # per-unit flags (none in use).  -DFQ30_ASM_CHAIN for msm_accum.hip was measured: the micro-benchmark's mixed-add ceiling
 # rises 7.0 -> 7.3-7.5 G/s (profiles/r02_ubench2_chain.txt) but the real accumulation kernel does not move in a same-box
 # A/B (profiles/r02_ab_chain_ntt.txt: 1.85-1.90 ms either way), so the compiler-scheduled form stays.

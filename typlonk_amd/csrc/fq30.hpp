@@ -305,105 +305,10 @@ TY_HD Fq30 fq30_mul2_add(const Fq30& a, const Fq30& b, const Fq30& c, const Fq30
     return fq30_redc(T);
 }
 
-// ---- the same products with instruction-level parallelism (latency-bound kernels) ----------------------------------
-// Every form above threads ONE 64-bit accumulator through all 26 columns: 351 multiply-adds, each waiting for the one
-// before.  That is the cheapest instruction stream, and with two wavefronts per SIMD the pipe is full anyway (the bucket
-// accumulation).  A LONE wavefront -- the dependent chains of the bucket reduction: msm_fold_seq, msm_rc2_planes, one wave per
-// SIMD or fewer -- pays the full latency of every multiply-add instead: ~2900 cycles per multiplication where the pipe price is
-// 1830.  Here every column has its own accumulator (25 independent chains of <= 13 products), the columns are cut into
-// UNSATURATED digits without a carry chain (digit k = low 30 bits of column k + middle 30 of column k - 1 + top 4 of
-// column k - 2, < 2^31.6), and the Montgomery digits m_k are the only serial thread left: m_k needs column k complete, and
-// each m_k feeds 13 independent columns.  More registers (irrelevant at one wavefront per SIMD), more instructions, a
-// much shorter critical path.  Same value, digit for digit (the Montgomery quotient is unique).
-// -DFQ30_ILP_MUL makes it the unit's fq30_mul / fq30_sqr / fq30_mul2_add (msm_reduce_chain.hip).
-TY_HD void fq30_digits_ilp(const Fq30& a, const Fq30& b, uint64_t (&r)[27]) {
-    uint64_t col[25];
-#pragma unroll
-    for (int k = 0; k < 25; ++k) col[k] = 0;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) {
-#pragma unroll
-        for (int j = 0; j < 13; ++j) col[i + j] += (uint64_t)a.v[i] * b.v[j];   // < 13 * 2^60 per column
-    }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        uint64_t d = 0;
-        if (k < 25) d += col[k] & FQ30_MASK;
-        if (k >= 1 && k - 1 < 25) d += (col[k - 1] >> 30) & FQ30_MASK;
-        if (k >= 2 && k - 2 < 25) d += col[k - 2] >> 60;
-        r[k] = d;
-    }
-}
-// a^2: the off-diagonal products once, against the doubled operand (2 a_i < 2^31: a column is < 7 * 2^61 < 2^64)
-TY_HD void fq30_sqr_digits_ilp(const Fq30& a, uint64_t (&r)[27]) {
-    uint64_t col[25];
-    uint32_t d2[13];
-#pragma unroll
-    for (int i = 0; i < 13; ++i) d2[i] = a.v[i] << 1;
-#pragma unroll
-    for (int k = 0; k < 25; ++k) col[k] = 0;
-#pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        col[2 * i] += (uint64_t)a.v[i] * a.v[i];
-#pragma unroll
-        for (int j = i + 1; j < 13; ++j) col[i + j] += (uint64_t)d2[i] * a.v[j];
-    }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        uint64_t d = 0;
-        if (k < 25) d += col[k] & FQ30_MASK;
-        if (k >= 1 && k - 1 < 25) d += (col[k - 1] >> 30) & FQ30_MASK;
-        if (k >= 2 && k - 2 < 25) d += col[k - 2] >> 60;
-        r[k] = d;
-    }
-}
-// Montgomery reduction of 27 unsaturated digits (each < 2^33, the value < 2^780): r[k + j] takes m_k p_j as soon as m_k
-// exists -- thirteen independent accumulators per digit; a column ends below 2^33 + 13 * 2^60 + 2^35 < 2^64.
-TY_HD Fq30 fq30_redc_ilp(uint64_t (&r)[27]) {
-    uint64_t carry = 0;
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        r[k] += carry;
-        const uint32_t m = ((uint32_t)r[k] * FQ30_NINV) & FQ30_MASK;
-#pragma unroll
-        for (int j = 0; j < 13; ++j) r[k + j] += (uint64_t)m * fq30_kp(1, j);
-        carry = r[k] >> 30;   // the low 30 bits are zero now
-    }
-    Fq30 o;
-#pragma unroll
-    for (int k = 13; k < 26; ++k) {
-        r[k] += carry;
-        o.v[k - 13] = (uint32_t)r[k] & FQ30_MASK;
-        carry = r[k] >> 30;
-    }
-    return o;
-}
-TY_HD Fq30 fq30_mul_ilp(const Fq30& a, const Fq30& b) {
-    uint64_t r[27];
-    fq30_digits_ilp(a, b, r);
-    return fq30_redc_ilp(r);
-}
-TY_HD Fq30 fq30_sqr_ilp(const Fq30& a) {
-    uint64_t r[27];
-    fq30_sqr_digits_ilp(a, r);
-    return fq30_redc_ilp(r);
-}
-TY_HD Fq30 fq30_mul2_add_ilp(const Fq30& a, const Fq30& b, const Fq30& c, const Fq30& d) {
-    uint64_t r[27], u[27];
-    fq30_digits_ilp(a, b, r);
-    fq30_digits_ilp(c, d, u);
-#pragma unroll
-    for (int k = 0; k < 27; ++k) r[k] += u[k];
-    return fq30_redc_ilp(r);
-}
-
 // ---- the multiplication the library uses ---------------------------------------------------------------
 // -DFQ30_SPLIT_MUL selects the two-phase form (product digits, then reduction) for A/B measurements
 // (tools/ubench2.hip); results are identical digit for digit.
-#if defined(FQ30_ILP_MUL)
-TY_HD Fq30 fq30_mul(const Fq30& a, const Fq30& b) { return fq30_mul_ilp(a, b); }
-TY_HD Fq30 fq30_sqr(const Fq30& a) { return fq30_sqr_ilp(a); }
-#elif defined(FQ30_SPLIT_MUL)
+#if defined(FQ30_SPLIT_MUL)
 TY_HD Fq30 fq30_mul(const Fq30& a, const Fq30& b) { return fq30_mul_split(a, b); }
 TY_HD Fq30 fq30_sqr(const Fq30& a) { return fq30_sqr_split(a); }
 #else

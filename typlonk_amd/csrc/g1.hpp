@@ -59,8 +59,6 @@ struct G1Xyzz {
 TY_HD Fq30 g1_y3(const Fq30& r, const Fq30& t, const Fq30& y, const Fq30& w) {
 #if defined(G1_SPLIT_Y3)
     return fq30_sub_lazy<2>(fq30_mul(r, t), fq30_mul(y, w));
-#elif defined(FQ30_ILP_MUL)
-    return fq30_mul2_add_ilp(r, t, fq30_neg_lazy<4>(y), w);
 #else
     return fq30_mul2_add(r, t, fq30_neg_lazy<4>(y), w);
 #endif

@@ -123,6 +123,7 @@ struct typlonk_buf {
 //   TYPLONK_MSM_CHUNKS    chunks of a stand-alone MSM (0 = by length)
 //   TYPLONK_MSM_LANES     lanes per bucket of the accumulation (1, 2, 4, 8, 16; 0 = by bucket load)
 //   TYPLONK_MSM_SCATTER   staged | direct: level 1 of the bucket sort stages its runs in the LDS / writes entry by entry
+//   TYPLONK_MSM_L1_THREADS 256 | 512: workgroup size of the sort's level-1 passes
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
 //   TYPLONK_NTT_FR30      0 | 1 | 2: the 9 x 30-bit butterflies never / where they measure faster / always
 //   TYPLONK_NTT_BIG       0 | 1 | 2: the two-pass 2^20 plan (4096-element tiles) never / where it measures faster / always
@@ -171,6 +172,7 @@ struct typlonk_ctx {
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_scatter_staged = true;  // TYPLONK_MSM_SCATTER=direct: level 1 of the bucket sort writes every entry straight to global
                                    // memory (the rounds 1-5 form, the A/B reference) instead of staging runs in the LDS
+    int msm_l1_threads = 256;      // TYPLONK_MSM_L1_THREADS = 256 | 512: threads per workgroup of the sort's level-1 passes (staged form)
     bool msm_rc4 = false;          // always the four-launch row/column reduction
     bool msm_rc2_force = false;    // the two-launch form for every bucket-set size
     // NTT

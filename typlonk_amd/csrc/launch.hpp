@@ -89,13 +89,14 @@ void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, ui
 void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint32_t* offsets, uint32_t* cursor,
                  hipStream_t s);
 uint32_t msm_segsort_blocks(uint64_t m);  // workgroups of the level-1 passes for an m-term MSM
+uint32_t msm_sched_words();               // words of the bucket-schedule counters (hist514 of the calls below)
 // the whole segmented bucket sort of one chunk, bucket schedule (order[]) included; blk_cnt: nseg * nblk words (the staged
 // level-1 scatter's per-workgroup count rows; NULL = direct scatter), seg_start: 2 * nseg words
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries, uint32_t* counts,
                         uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks,
-                        uint32_t* order, bool centred, int staged_mode, hipStream_t s);
+                        uint32_t* order, bool centred, int staged_mode, uint32_t l1_threads, hipStream_t s);
 // windows of the signed c-bit digit decomposition.  Scalars are canonical (< r < 2^255): the top window holds
 // t = bits - c (W0 - 1) bits, W0 = ceil(bits / c), and a digit <= 2^t cannot exceed 2^(c-1) (no carry out of it) unless
 // t = c.  Centred scalars (|k| <= (r - 1)/2 < 2^254) have one bit less: c = 17 -> 15 windows instead of 16.
@@ -154,9 +155,6 @@ TY_HD uint32_t rc_weight(const RcShape& sh, uint32_t set, uint32_t kind, uint32_
     if (v <= sh.cl) return kind == 0 ? idx : (idx >> v) + 1;
     return kind == 0 ? (idx >> (v - sh.cl)) + 1 : 0u;
 }
-// first launch of the four-launch reduction: row partials (nrow threads, padded to nrow_pad) and column partials (ncol)
-void launch_msm_rc_partial(const uint32_t* buckets, const RcShape& sh, uint32_t nrow, uint32_t nrow_pad, uint32_t ncol, uint32_t* pb,
-                           uint32_t* pa, hipStream_t s);
 void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* pb, uint32_t* pa, uint32_t* sums,
                           uint32_t* bitsum, uint32_t* out, hipStream_t s);
 // the same bit planes in two launches (msm_reduce.hip); needs cl, ch >= 6; prow, pcol: nsets << (c1 - 6) points each

@@ -152,7 +152,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if ((rc = ensure(ctx, sb.cursor, nb * 4))) return rc;
         if ((rc = ensure(ctx, sb.blocksums, (size_t)scan_blocks * 4))) return rc;
         if ((rc = ensure(ctx, sb.order, nb * 4))) return rc;
-        if ((rc = ensure(ctx, sb.ohist, 516 * 4))) return rc;
+        if ((rc = ensure(ctx, sb.ohist, (size_t)msm_sched_words() * 4))) return rc;
         // heavy-bucket splitting: cap = entries one thread may sum; at most total/cap heavy buckets/tasks
         // 8 x the mean, at least 32 (round 2: 4 x the mean, at least 512).  The accumulate kernel's thread walks a bucket's
         // first cap entries one after the other -- 6.7 us each when it is the last one running -- so a few buckets of 500
@@ -188,7 +188,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
                                tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums,
                                (uint32_t*)sb.blk_cnt.p, (uint32_t*)sb.seg_start.p, keys, counts, offsets, sorted, cap,
                                (uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, (uint32_t*)sb.order.p,
-                               centred, ctx->msm_scatter_staged ? 1 : 0, ss);
+                               centred, ctx->msm_scatter_staged ? 1 : 0, (uint32_t)ctx->msm_l1_threads, ss);
         } else {
             {
                 StageTimer st(ctx, "msm_digits", ss);

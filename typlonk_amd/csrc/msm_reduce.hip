@@ -1,11 +1,4 @@
 // MSM bucket reduction: per bucket set sum_k w(k)*B_k by the row/column split (launch.hpp) + wavefront butterflies.
-//
-// Everything in this unit is a DEPENDENT CHAIN run by one wavefront per SIMD or fewer (fold, bit planes, combine: 55 % and
-// 4 % VALU utilisation in profiles/r05_*): what bounds it is the latency of a field multiplication, not its instruction
-// count.  The unit therefore takes the column-parallel form of the multiplication (fq30.hpp, fq30_mul_ilp: ~1.5 x shorter
-// critical path, same digits); the one throughput-bound kernel of the reduction, msm_rc_partial_kernel, lives in
-// msm_rc_partial.hip with the single-accumulator form the bucket accumulation uses.
-#define FQ30_ILP_MUL 1
 #include "launch.hpp"
 #include "msm_common.hpp"
 
@@ -20,15 +13,43 @@ namespace ty {
 // 3. msm_rc_bits_kernel     one wavefront per (set, kind, weight bit, 64-item chunk): butterfly sum of the
 //    items whose weight has that bit set.
 // 4. msm_rc_final_kernel    one wavefront per (set, kind, bit): sum over the chunks.
+__global__ __launch_bounds__(64) void msm_rc_partial_kernel(const uint32_t* __restrict__ buckets, RcShape sh,
+                                                            uint32_t nrow, uint32_t nrow_pad, uint32_t ncol,
+                                                            uint32_t* pb, uint32_t* pa) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t < nrow_pad) {
+        if (t >= nrow) return;
+        const uint64_t base = (uint64_t)t << sh.llc;
+        G1Xyzz v = ld_xyzz(buckets, base);
+        for (uint32_t l = 1; l < (1u << sh.llc); ++l) v = g1_add(v, ld_xyzz(buckets, base + l));
+        st_xyzz(pb, t, v);
+        return;
+    }
+    const uint32_t u = t - nrow_pad;
+    if (u >= ncol) return;
+    const uint32_t per_set = sh.c1 - sh.lhc;
+    const uint32_t set = u >> per_set, rem = u & ((1u << per_set) - 1);
+    const uint32_t lo = rem & ((1u << sh.cl) - 1), hchunk = rem >> sh.cl;
+    const uint64_t first = ((uint64_t)set << sh.c1) + ((uint64_t)(hchunk << sh.lhc) << sh.cl) + lo;
+    G1Xyzz v = ld_xyzz(buckets, first);
+    for (uint32_t h = 1; h < (1u << sh.lhc); ++h) v = g1_add(v, ld_xyzz(buckets, first + ((uint64_t)h << sh.cl)));
+    st_xyzz(pa, ((((uint64_t)set << sh.cl) + lo) << (sh.ch - sh.lhc)) + hchunk, v);
+}
+
 struct FoldSeg {
     const uint32_t* in;
     uint32_t* out;
     uint32_t threads, lseq, lanes;
 };
-__global__ __launch_bounds__(64) void msm_fold_seq_kernel(FoldSeg a, FoldSeg b, uint32_t blocks_a) {
-    const bool first = blockIdx.x < blocks_a;
+// (workgroups of four wavefronts, one per SIMD of a CU, each wavefront working alone: with one-wavefront workgroups the
+// dispatcher stacks two wavefronts of a one-per-SIMD launch on one SIMD now and then and leaves another idle -- seen on
+// msm_rc2_sums_kernel, 112 us instead of 76)
+__global__ __launch_bounds__(256) void msm_fold_seq_kernel(FoldSeg a, FoldSeg b, uint32_t waves_a, uint32_t waves) {
+    const uint32_t wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= waves) return;   // whole wavefronts only
+    const bool first = wv < waves_a;
     const FoldSeg& g = first ? a : b;
-    const uint32_t t = (blockIdx.x - (first ? 0u : blocks_a)) * 64 + threadIdx.x;
+    const uint32_t t = (wv - (first ? 0u : waves_a)) * 64 + (threadIdx.x & 63u);
     G1Xyzz v = G1Xyzz::inf();
     if (t < g.threads) {
         const uint64_t base = (uint64_t)t << g.lseq;
@@ -36,7 +57,7 @@ __global__ __launch_bounds__(64) void msm_fold_seq_kernel(FoldSeg a, FoldSeg b, 
         for (uint32_t i = 1; i < (1u << g.lseq); ++i) v = g1_add(v, ld_xyzz(g.in, base + i));
     }
     for (uint32_t mask = 1; mask < g.lanes; mask <<= 1) v = butterfly_add(v, (int)mask);
-    if (t < g.threads && (threadIdx.x & (g.lanes - 1)) == 0) st_xyzz(g.out, t / g.lanes, v);
+    if (t < g.threads && (t & (g.lanes - 1)) == 0) st_xyzz(g.out, t / g.lanes, v);
 }
 
 // sums: row sums [set][hi] (nsets * R points) followed by column sums [set][lo]
@@ -231,7 +252,8 @@ void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* 
                           uint32_t* bitsum, uint32_t* out, hipStream_t s) {
     const uint32_t nrow = sh.nsets << (sh.c1 - sh.llc), ncol = sh.nsets << (sh.c1 - sh.lhc);
     const uint32_t nrow_pad = (nrow + 63) & ~63u;
-    launch_msm_rc_partial(buckets, sh, nrow, nrow_pad, ncol, pb, pa, s);
+    hipLaunchKernelGGL(msm_rc_partial_kernel, dim3((nrow_pad + ncol + 63) / 64), dim3(64), 0, s, buckets, sh, nrow, nrow_pad,
+                       ncol, pb, pa);
     // row partials: 2^(cl - llc) per row; column partials: 2^(ch - lhc) per column
     auto seg = [](const uint32_t* in, uint32_t* out, uint32_t n_in, uint32_t lcnt) {
         FoldSeg g;
@@ -246,7 +268,7 @@ void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* 
     uint32_t* csum = sums + ((uint64_t)sh.nsets << sh.ch) * 48;
     const FoldSeg a = seg(pb, rsum, nrow, sh.cl - sh.llc), b = seg(pa, csum, ncol, sh.ch - sh.lhc);
     const uint32_t ba = (a.threads + 63) / 64, bb = (b.threads + 63) / 64;
-    hipLaunchKernelGGL(msm_fold_seq_kernel, dim3(ba + bb), dim3(64), 0, s, a, b, ba);
+    hipLaunchKernelGGL(msm_fold_seq_kernel, dim3((ba + bb + 3) / 4), dim3(256), 0, s, a, b, ba, ba + bb);
     if (sh.ch >= 6 && sh.cl >= 6) {
         // the bit planes of the R + C sums in ONE launch (msm_rc2_planes_kernel with one "partial" per row / column):
         // a workgroup per (set, kind, bit) butterfly-sums the selected sums per wavefront and across wavefronts

@@ -349,8 +349,10 @@ __global__ __launch_bounds__(256) void msm_seg_prefix_kernel(const uint32_t* __r
                                                              uint32_t nzero) {
     __shared__ uint32_t buf[256];
     __shared__ uint32_t running;
-    if (blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+    {   // every workgroup clears its slice
+        const uint32_t per = (nzero + gridDim.x - 1) / gridDim.x;
+        for (uint32_t i = blockIdx.x * per + threadIdx.x; i < min((blockIdx.x + 1) * per, nzero); i += 256) zero[i] = 0;
+    }
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
     const uint64_t row = (uint64_t)blockIdx.x * nblk;
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(1024) void msm_seg_scatter_kernel(const Fr* scalars
 // runs of <= 64 contiguous bytes, and a run's cache lines are written once.
 // LDS: nseg running ranks | nseg local starts | nseg global starts | the staging area (chunk * W entries).
 template <uint32_t C>
-__global__ __launch_bounds__(256) void msm_seg_scatter_staged_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
+__global__ __launch_bounds__(512) void msm_seg_scatter_staged_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
                                                                      const uint32_t* __restrict__ blk_base,
                                                                      const uint32_t* __restrict__ seg_tot,
                                                                      const uint32_t* __restrict__ blk_cnt, uint32_t* seg_start,
@@ -541,6 +543,16 @@ __global__ __launch_bounds__(256) void msm_seg_scatter_staged_kernel(const Fr* s
 //                         256-bin histogram for itself and claims its run inside each bin from a global cursor).  The claim's
 //                         round trip to the L2 hides under the placement loop.
 // 256, 512 or 1024 threads: all of them walk the segment, the first 256 own the 2^lb <= 256 buckets.
+// Schedule counters of the segmented sort.  Words [0, 516) keep the layout of the atomic sort's hist514 ([512] heavy buckets,
+// [513] tasks -- msm_heavy_kernel reads those); the size histogram and the claim cursors of the SEGMENTED sort are kept in
+// MSM_SCHED_REPLICAS copies behind them, replica r = segment mod R at word 1024 + 512 r (256 bins + 256 cursors, a KiB apart).
+// Why: ~25 size bins are hot, adjacent words of ONE cache line, and every one of the 2048-4096 level-2 workgroups adds
+// to each of them -- 51 K atomics on one line, which the L2 retires one per clock: ~24 us per launch, the whole run time of
+// order_fused_kernel in rounds 1-5 and most of msm_seg_count / msm_seg_place.  Sixteen lines take them sixteen at a time.
+constexpr uint32_t MSM_SCHED_REPLICAS = 16;
+constexpr uint32_t MSM_SCHED_WORDS = 1024 + 512 * MSM_SCHED_REPLICAS;
+uint32_t msm_sched_words() { return MSM_SCHED_WORDS; }
+
 // inclusive scan over the values of threads 0..255 (four wavefronts): shuffles inside a wavefront, one LDS hand-over
 // between them -- two barriers where the Hillis-Steele form over LDS takes sixteen.  Every thread of the workgroup calls it.
 __device__ __forceinline__ uint32_t msm_scan256_incl(uint32_t v, uint32_t* wsum /* 4 words of LDS */) {
@@ -619,7 +631,7 @@ __global__ __launch_bounds__(1024) void msm_seg_count_kernel(const uint32_t* __r
     __syncthreads();
     if (tid < 256) {
         const uint32_t nbin = hist[tid];
-        if (nbin) atomicAdd(&ohist[tid], nbin);
+        if (nbin) atomicAdd(&ohist[1024 + 512 * (s & (MSM_SCHED_REPLICAS - 1)) + tid], nbin);
     }
 }
 
@@ -627,7 +639,7 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
                                                              const uint32_t* __restrict__ seg_start, MsmShape sh,
                                                              const uint32_t* __restrict__ counts,
                                                              const uint32_t* __restrict__ offsets, uint32_t* sorted,
-                                                             const uint32_t* __restrict__ ohist, uint32_t* gcur, uint32_t* order) {
+                                                             uint32_t* sched, uint32_t* order) {
     __shared__ uint32_t cur[256];    // running rank inside each bucket
     __shared__ uint32_t pref[256];   // the bucket's start inside the segment
     __shared__ uint32_t wsum[4];
@@ -638,10 +650,17 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
     const uint32_t nlow = 1u << sh.lb;
     uint32_t key = 0, rank = 0, bucket = 0, v = 0;
     const uint32_t k = 255 - tid;  // thread t scans size key 255 - t (descending order)
+    const uint32_t rep = s & (MSM_SCHED_REPLICAS - 1);
+    uint32_t before = 0;   // buckets of this size in the replicas before this segment's
     if (tid < 256) {
         cur[tid] = 0;
         h[tid] = 0;
-        v = ohist[k];
+#pragma unroll
+        for (uint32_t r = 0; r < MSM_SCHED_REPLICAS; ++r) {
+            const uint32_t c = sched[1024 + 512 * r + k];
+            v += c;
+            before += r < rep ? c : 0u;
+        }
         if (tid < nlow) {
             bucket = s * nlow + tid;
             pref[tid] = offsets[bucket] - start;
@@ -652,7 +671,7 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
     if (tid < nlow) rank = atomicAdd(&h[key], 1u);
     const uint32_t larger = msm_scan256_incl(v, wsum) - v;   // buckets with a larger size key (the scan has two barriers: h[] is complete)
     // claim this segment's run inside every occupied bin (the answer is needed only after the placement loop)
-    if (tid < 256) blk[k] = larger + (h[k] ? atomicAdd(&gcur[k], h[k]) : 0u);
+    if (tid < 256) blk[k] = larger + before + (h[k] ? atomicAdd(&sched[1024 + 512 * rep + 256 + k], h[k]) : 0u);
     const uint32_t low_sh = sh.ibits + sh.jbits + 1;
     for (uint32_t e = start + tid; e < end; e += nt) {
         const uint32_t x = entries[e];
@@ -779,7 +798,7 @@ uint32_t msm_segsort_blocks(uint64_t m) { return (uint32_t)((m + msm_chunk_for(m
 // LDS of the staged scatter: three arrays of nseg words + the staging area; it is taken when that fits the 160 KiB of a CU
 // (table mode c = 20: 2048 scalars x 13 windows = 104 KiB + 24-48 KiB) and the fused row-prefix form applies
 static size_t msm_staged_lds(const MsmShape& sh) {
-    return ((size_t)3 * sh.nseg + std::max<size_t>((size_t)sh.chunk * sh.W, 512)) * sizeof(uint32_t);   // (>= the scans' scratch)
+    return ((size_t)3 * sh.nseg + std::max<size_t>((size_t)sh.chunk * sh.W, 1024)) * sizeof(uint32_t);   // (>= the scans' scratch)
 }
 template <uint32_t C>
 static bool msm_staged_raise_lds() {
@@ -797,9 +816,12 @@ template <uint32_t C>
 static void launch_msm_segsort_c(const Fr* scalars, uint64_t m, const MsmShape& sh, uint32_t* blk_hist, uint32_t* blk_base,
                                  uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries,
                                  uint32_t* counts, uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514,
-                                 uint32_t* heavy, uint32_t* tasks, uint32_t* order, int staged_mode, hipStream_t s) {
+                                 uint32_t* heavy, uint32_t* tasks, uint32_t* order, int staged_mode, uint32_t l1_threads,
+                                 hipStream_t s) {
     const uint64_t nmat = (uint64_t)sh.nseg * sh.nblk;
     const uint32_t nt1 = msm_seg1_threads();
+    // threads of the staged scatter and of the histogram beside it: 256 (one wavefront per SIMD) or 512 where the chunk divides
+    const uint32_t nts = (l1_threads == 512 && sh.chunk % 512 == 0) ? 512u : 256u;
     // the fused row-prefix form scans the segment totals in LDS next to the scatter's cursors (nseg + nt1 words); wider
     // segment sets take the three-launch scan of the whole workgroup x segment matrix
     const bool fused = sh.nseg <= 8192;
@@ -807,15 +829,15 @@ static void launch_msm_segsort_c(const Fr* scalars, uint64_t m, const MsmShape& 
     const size_t lds_staged = msm_staged_lds(sh);
     const bool staged = staged_mode != 0 && fused && blk_cnt && lds_staged <= 160 * 1024 &&
                         (lds_staged <= 64 * 1024 || msm_staged_raise_lds<C>());
-    hipLaunchKernelGGL(msm_seg_hist_kernel<C>, dim3(sh.nblk), dim3(nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh, blk_hist,
-                       staged ? blk_cnt : (uint32_t*)nullptr);
+    hipLaunchKernelGGL(msm_seg_hist_kernel<C>, dim3(sh.nblk), dim3(staged ? nts : nt1), sh.nseg * sizeof(uint32_t), s, scalars, m, sh,
+                       blk_hist, staged ? blk_cnt : (uint32_t*)nullptr);
     if (fused)
         hipLaunchKernelGGL(msm_seg_prefix_kernel, dim3(sh.nseg), dim3(256), 0, s, blk_hist, sh.nblk, blk_base, seg_tot, hist514,
-                           516u);
+                           MSM_SCHED_WORDS);
     else
-        launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, 516u, s);
+        launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, MSM_SCHED_WORDS, s);
     if (staged)
-        hipLaunchKernelGGL(msm_seg_scatter_staged_kernel<C>, dim3(sh.nblk), dim3(256), lds_staged, s, scalars, m, sh, blk_base, seg_tot,
+        hipLaunchKernelGGL(msm_seg_scatter_staged_kernel<C>, dim3(sh.nblk), dim3(nts), lds_staged, s, scalars, m, sh, blk_base, seg_tot,
                            blk_cnt, seg_start, entries);
     else
         hipLaunchKernelGGL(msm_seg_scatter_kernel<C>, dim3(sh.nblk), dim3(nt1), (fused ? sh.nseg + nt1 : sh.nseg) * sizeof(uint32_t),
@@ -826,7 +848,7 @@ static void launch_msm_segsort_c(const Fr* scalars, uint64_t m, const MsmShape& 
     hipLaunchKernelGGL(msm_seg_count_kernel, dim3(sh.nseg), dim3(nt2), 0, s, entries, blk_base, seg_tot, sh, (uint32_t)nmat,
                        counts, offsets, seg_start, cap, hist514, heavy, tasks);
     hipLaunchKernelGGL(msm_seg_place_kernel, dim3(sh.nseg), dim3(nt2), 0, s, entries, seg_start, sh, counts, offsets, sorted,
-                       hist514, hist514 + 256, order);
+                       hist514, order);
 }
 
 // The whole bucket sort of one chunk of terms, bucket schedule (order[]) included.  staged_mode: 0 = the direct level-1
@@ -835,7 +857,7 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries, uint32_t* counts,
                         uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks,
-                        uint32_t* order, bool centred, int staged_mode, hipStream_t s) {
+                        uint32_t* order, bool centred, int staged_mode, uint32_t l1_threads, hipStream_t s) {
     MsmShape sh;
     sh.centred = centred ? 1u : 0u;
     sh.c = c;
@@ -851,7 +873,7 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
     sh.chunk = msm_chunk_for(m);
     sh.nblk = (uint32_t)((m + sh.chunk - 1) / sh.chunk);
 #define TY_SEGSORT(C) launch_msm_segsort_c<C>(scalars, m, sh, blk_hist, blk_base, scan_scratch, blk_cnt, seg_start, entries, counts, \
-                                              offsets, sorted, cap, hist514, heavy, tasks, order, staged_mode, s)
+                                              offsets, sorted, cap, hist514, heavy, tasks, order, staged_mode, l1_threads, s)
     // the table windows get the constant-width digit extraction; every other width the run-time form
     if (c == 20) TY_SEGSORT(20);
     else if (c == 17) TY_SEGSORT(17);
