@@ -407,6 +407,30 @@ def test_public_header_is_plain_c99_and_cxx11(tmp_path):
         assert r.returncode == 0, r.stderr
 
 
+def test_scale_table_reads_bench_lines(tmp_path):
+    """tools/scale_table.py (arrival day of a multi-GPU box): measured speed-ups per mode next to the one-GPU projection, and a
+    note when the exchange did not run over the library's own communicator"""
+    import json
+    import subprocess
+    import sys
+
+    d1 = {"n_gpus": 1, "ms_per_step": 2.6, "msm_batch": {"ms_per_msm": 2.4}, "prove_native_ms": 36.0, "rccl_world": 0}
+    d8 = {"n_gpus": 8, "ms_per_step": 0.65, "msm_batch": {"ms_per_msm": 0.4}, "prove_sharded_native_ms": 10.0, "rccl_world": 8,
+          "expected_from_1gpu": {"one_msm_plus_exchange_ms": 0.59, "batched_ms_per_msm": 0.417, "prove_on_shard_ms": 10.3,
+                                 "speedup": {"one_msm": 4.4, "batched_msms": 5.9, "prove": 3.6}}}
+    d2 = {"n_gpus": 2, "ms_per_step": 1.5, "msm_batch": {"ms_per_msm": 1.25}, "rccl_world": 0}
+    paths = []
+    for d in (d1, d8, d2):
+        p = tmp_path / f"{d['n_gpus']}.json"
+        p.write_text("log noise\n" + json.dumps(d) + "\n")
+        paths.append(str(p))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_table.py"), *paths], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = {l.split()[0]: l for l in r.stdout.splitlines() if l[:3].strip().isdigit()}
+    assert "4.00" in rows["8"] and "6.00" in rows["8"] and "3.60" in rows["8"] and "5.90" in rows["8"]    # measured and projected
+    assert "1.73" in rows["2"] and "NOTE: N = [2]" in r.stdout
+
+
 def test_bench_without_a_launcher_still_ends_with_one_contract_line(built):
     """`python bench.py --gpus 2` with no torch.distributed.run around it starts its own rank processes; without a GPU
     (this suite) the ranks fail loudly -- no CPU fallback -- and the parent still ends with ONE contract line that

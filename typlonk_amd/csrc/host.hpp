@@ -172,7 +172,9 @@ struct typlonk_ctx {
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_scatter_staged = true;  // TYPLONK_MSM_SCATTER=direct: level 1 of the bucket sort writes every entry straight to global
                                    // memory (the rounds 1-5 form, the A/B reference) instead of staging runs in the LDS
-    int msm_l1_threads = 256;      // TYPLONK_MSM_L1_THREADS = 256 | 512: threads per workgroup of the sort's level-1 passes (staged form)
+    int msm_l1_threads = 512;      // TYPLONK_MSM_L1_THREADS = 256 | 512: threads per workgroup of the sort's level-1 passes (staged form);
+                                   // 512 (two wavefronts per SIMD): histogram 18.5 -> 14.3 us, scatter 49.3 -> 32.6 us per 2^19 terms,
+                                   // nine-MSM batch 2.494 -> 2.477 ms per MSM (profiles/r06_ab_sort.txt)
     bool msm_rc4 = false;          // always the four-launch row/column reduction
     bool msm_rc2_force = false;    // the two-launch form for every bucket-set size
     // NTT

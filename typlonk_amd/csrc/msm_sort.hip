@@ -595,7 +595,16 @@ __global__ __launch_bounds__(1024) void msm_seg_count_kernel(const uint32_t* __r
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const uint32_t low_sh = sh.ibits + sh.jbits + 1;
-    for (uint32_t e = start + tid; e < end; e += nt) atomicAdd(&hist[entries[e] >> low_sh], 1u);
+    // (eight loads in flight per thread: a thread walks ~13 entries of its segment, and one load per trip of a loop whose
+    // trip count the compiler does not know was one exposed L2 round trip each)
+    for (uint32_t e0 = start + tid; e0 < end; e0 += 8 * nt) {
+        uint32_t x[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) x[u] = e0 + u * nt < end ? entries[e0 + u * nt] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u)
+            if (e0 + u * nt < end) atomicAdd(&hist[x[u] >> low_sh], 1u);
+    }
     __syncthreads();
     const uint32_t mine = tid < 256 ? hist[tid] : 0;
     const uint32_t excl = msm_scan256_incl(mine, wsum) - mine;
@@ -673,14 +682,22 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
     // claim this segment's run inside every occupied bin (the answer is needed only after the placement loop)
     if (tid < 256) blk[k] = larger + before + (h[k] ? atomicAdd(&sched[1024 + 512 * rep + 256 + k], h[k]) : 0u);
     const uint32_t low_sh = sh.ibits + sh.jbits + 1;
-    for (uint32_t e = start + tid; e < end; e += nt) {
-        const uint32_t x = entries[e];
-        const uint32_t b = x >> low_sh;
-        const uint32_t r = atomicAdd(&cur[b], 1u);
-        const uint32_t i = x & ((1u << sh.ibits) - 1);
-        const uint32_t j = (x >> sh.ibits) & ((1u << sh.jbits) - 1);
-        const uint32_t neg = (x >> (sh.ibits + sh.jbits)) & 1u;
-        sorted[start + pref[b] + r] = (j * sh.tlen + i) | (neg << 31);
+    for (uint32_t e0 = start + tid; e0 < end; e0 += 8 * nt) {   // (eight loads in flight, as in the count kernel)
+        uint32_t xs[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) xs[u] = e0 + u * nt < end ? entries[e0 + u * nt] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            if (e0 + u * nt < end) {
+                const uint32_t x = xs[u];
+                const uint32_t b = x >> low_sh;
+                const uint32_t r = atomicAdd(&cur[b], 1u);
+                const uint32_t i = x & ((1u << sh.ibits) - 1);
+                const uint32_t j = (x >> sh.ibits) & ((1u << sh.jbits) - 1);
+                const uint32_t neg = (x >> (sh.ibits + sh.jbits)) & 1u;
+                sorted[start + pref[b] + r] = (j * sh.tlen + i) | (neg << 31);
+            }
+        }
     }
     __syncthreads();
     if (tid < nlow) order[blk[key] + rank] = bucket;
