@@ -22,7 +22,7 @@ def main():
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(src))}
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(cc)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if not name.startswith("ty::"):
             continue
         key = (name, r["Grid_Size"], r["Dispatch_Id"])
@@ -43,6 +43,8 @@ def main():
         out[f"{name} grid={grid}"] = {
             "launches": n, "avg_us": round(du / 1e3, 1), "effective_clock_ghz": round(clk, 2),
             "valu_util": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / avail, 3),
+            # VALU instructions a wavefront executes in this launch (SQ_INSTS_VALU counts wave-instructions over the chip)
+            "valu_insts_per_wavefront": round(c.get("SQ_INSTS_VALU", 0.0) / max(1.0, int(grid) / 64.0), 1),
             "wave_cycles_active": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3),
             "wave_cycles_issue_stall": round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3),
             "wave_cycles_parked": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)}
