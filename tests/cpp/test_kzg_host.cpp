@@ -104,6 +104,18 @@ static void interpolate_then_commit(const Context& ctx) {
     poly::Radix2EvaluationDomain d4(ctx, 4);
     Poly q = poly::interpolate(d4.fft(c), d4);
     REQUIRE(q.coeffs.size() == 2 && q.degree() == 1);
+    // a GROUP of columns through one batched transform (builder.rs:84-88) == the columns one by one
+    {
+        std::vector<std::vector<Fr>> cols(5, std::vector<Fr>(n));
+        Fr y(11);
+        for (auto& col : cols)
+            for (auto& e : col) { e = y; y = y * y + Fr(3); }
+        cols[4].assign(n, Fr(0));                       // an all-zero selector: the zero polynomial after the trim
+        cols[3] = domain.fft({Fr(9), Fr(4)});           // degree 1: trailing zeros trimmed
+        auto polys = poly::interpolate_batch(ctx, cols, domain);
+        REQUIRE(polys.size() == 5 && polys[4].is_zero() && polys[3].coeffs.size() == 2 && polys[3].coeffs[1] == Fr(4));
+        for (int k = 0; k < 5; ++k) REQUIRE(polys[k].coeffs == poly::interpolate(cols[k], domain).coeffs);
+    }
     // domain construction beyond the two-adicity fails like GeneralEvaluationDomain::new(..).unwrap()
     bool threw = false;
     try { poly::Radix2EvaluationDomain too_big(ctx, (1ull << 32) + 1); } catch (const std::runtime_error&) { threw = true; }

@@ -126,7 +126,6 @@ struct typlonk_buf {
 //   TYPLONK_MSM_L1_THREADS 256 | 512: workgroup size of the sort's level-1 passes
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
 //   TYPLONK_NTT_FR30      0 | 1 | 2: the 9 x 30-bit butterflies never / where they measure faster / always
-//   TYPLONK_NTT_L9        0 | 1: inter-pass data of the 30-bit kernel packed into eight words / kept as nine limbs (36 B)
 //   TYPLONK_NTT_BIG       0 | 1 | 2: the two-pass 2^20 plan (4096-element tiles) never / where it measures faster / always
 //   TYPLONK_PROVER_NTT_BATCH 0 | 1 | 2: round 1 transforms its columns one by one (each commitment submitted as soon as its
 //                         polynomial exists) / as one batched transform per group (ntt_run_batch) / the first alone, the rest batched
@@ -190,7 +189,6 @@ struct typlonk_ctx {
     static constexpr size_t COSET_BYTES_MAX = (size_t)3 << 30;
     int ntt_fr30 = 1;              // 0 = the 8 x 32-bit kernel everywhere, 1 = the default policy (9 x 30-bit butterflies, fr30.hpp, for
                                    // every inverse transform and for forward ones up to 2^NTT_FR30_FWD_MAX_LOG), 2 = 30-bit everywhere
-    bool ntt_l9 = true;            // TYPLONK_NTT_L9: the 30-bit kernel keeps nine limbs per element between its passes (ntt_run_batch)
     int ntt_big = 1;               // TYPLONK_NTT_BIG: the two-pass 2^20 plan on 4096-element tiles 0 = never, 1 = where it measures
                                    // faster (ntt_run_batch), 2 = for every 2^20 transform outside a prover round
     // profiling

@@ -81,8 +81,7 @@ bool ntt_big_tiles_available();
 void launch_ntt_pass(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);
 // the same pass on 9 x 30-bit limbs: every table in `a` is a full table in the 2^270 domain, 36 B of LDS per element
 void launch_ntt_pass30(const NttPassArgs& a, unsigned blocks, unsigned threads, size_t lds_bytes, hipStream_t s);
-// l9: the table as nine 30-bit limbs per entry on a 36-byte stride (out: n * 36 bytes) instead of eight words
-void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n, Fr* out, bool l9, hipStream_t s);
+void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n, Fr* out, hipStream_t s);
 
 void launch_convert_points(uint32_t* pts, const uint8_t* inf, uint64_t n, hipStream_t s);
 void launch_msm_digits(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t* keys,

@@ -152,4 +152,84 @@ __device__ __forceinline__ G1Xyzz butterfly_add(const G1Xyzz& v, int mask) {
     return out;
 }
 
+// ---- the same step with one addition split over FOUR lanes (mask >= 2) ------------------------------------------------------
+// From the second step of a butterfly on, lanes l and l ^ 1 hold the SAME point (both ended the step before with the sum), so
+// the two points of a step live on four lanes: A on {q0, q1}, B = the (l ^ mask) side on {q2, q3}.  add-2008-s is four
+// multiplications deep (U -> PP -> PPP -> Y3), and with four lanes it is four ROUNDS of one multiplication per lane where
+// the lane pair needs seven.  The chains of the bucket reduction (msm_fold_seq, msm_rc2_planes, msm_rc2_sums: one wavefront
+// per SIMD or fewer) pay the latency of every multiplication in full, so a step goes from 7 multiplication times + 8 field
+// exchanges to 4 + 11.
+//   round 1   q0: U1 = X_A ZZ_B    q1: S1 = Y_A ZZZ_B    q2: U2 = X_B ZZ_A    q3: S2 = Y_B ZZZ_A       (1 exchange before)
+//   round 2   q0: ZZ12             q1: ZZZ12             q2: PP = P^2         q3: RR = R^2             (P = U2 - U1 on the even,
+//             R = S2 - S1 on the odd lanes: both sides can form them after one exchange of the round-1 products)
+//   round 3   q0: Q = U1 PP        q1: --                q2: PPP = P PP       q3: --                   (1 exchange: PP <-> ZZ12)
+//   round 4   q0: ZZ3 = ZZ12 PP    q1: R (Q - X3)        q2: ZZZ3 = ZZZ12 PPP q3: S1 PPP               (3 exchanges)
+// and a gather of X3, Y3 = R(Q - X3) - S1 PPP, ZZ3, ZZZ3 onto all four lanes (5 exchanges).  Bounds: those of butterfly_add.
+// Identity operands, equal and opposite points are settled at the end exactly as there (every lane of a side holds the
+// whole point, so each lane settles its own copy).  Precondition: v is identical on lanes l and l ^ 1.
+__device__ __forceinline__ Fq30 shfl_fq(const Fq30& a, int src_lane) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) r.v[i] = __shfl(a.v[i], src_lane);
+    return r;
+}
+__device__ __forceinline__ G1Xyzz butterfly_add4(const G1Xyzz& v, int mask) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool odd = (lane & 1) != 0, bside = (lane & mask) != 0;
+    const int qbase = lane & ~(mask | 1);
+    const int l0 = qbase, l1 = qbase | 1, l2 = qbase | mask, l3 = qbase | mask | 1;   // the lanes holding roles q0..q3
+    const bool v_inf = v.is_inf();
+    const bool o_inf = __shfl_xor((int)v_inf, mask) != 0;
+    // round 1
+    const Fq30 send = fq_sel(odd, v.zzz, v.zz);
+    const Fq30 recv1 = shfl_xor_fq(send, mask);                               // the other point's ZZ (even lanes) / ZZZ (odd)
+    const Fq30 m1 = fq30_mul(fq_sel(odd, v.y, v.x), recv1);                   // U1 | S1 | U2 | S2   < 1.01
+    // round 2
+    const Fq30 x1 = shfl_xor_fq(m1, mask);                                    // U2 | S2 | U1 | S1
+    const Fq30 d = fq30_sub_lazy<2>(fq_sel(bside, m1, x1), fq_sel(bside, x1, m1));   // P (even lanes) | R (odd lanes)   < 3.1
+    const Fq30 m2 = fq30_mul(fq_sel(bside, d, send), fq_sel(bside, d, recv1));       // ZZ12 | ZZZ12 | PP | RR   < 1.02
+    // equal or opposite points (P = 0); and R = 0: the same point
+    const bool z2 = fq30_is_zero_mod(m2);
+    const bool exc = !v_inf && !o_inf && (__shfl((int)z2, l2) != 0);
+    const bool same = __shfl((int)z2, l3) != 0;
+    // round 3 (even lanes; the odd lanes' product is not used)
+    const Fq30 x2 = shfl_xor_fq(m2, mask);                                    // PP | RR | ZZ12 | ZZZ12
+    const Fq30 m3 = fq30_mul(fq_sel(bside, d, m1), fq_sel(bside, m2, x2));    // Q = U1 PP | -- | PPP = P PP | --   < 1.01
+    // round 4
+    const Fq30 a = shfl_xor_fq(m3, 1);                                        // -- | Q | -- | PPP
+    const Fq30 b = shfl_xor_fq(m3, mask ^ 1);                                 // -- | PPP | -- | Q
+    const Fq30 c = shfl_xor_fq(x2, 1);                                        // (q2 takes ZZZ12 from q3)
+    // q1: X3 = RR - PPP - 2Q (RR = x2, PPP = b, Q = a), T = Q - X3
+    const Fq30 x3 = fq30_sub2_lazy<4>(x2, b, fq30_mulk_lazy<2>(a));           // < 5.1 (on q1; elsewhere unused)
+    const Fq30 t = fq30_sub_lazy<6>(a, x3);                                   // < 7.1
+    Fq30 opa, opb;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        // q0: ZZ12 PP = m2 x2;  q1: R T = d t;  q2: ZZZ12 PPP = c m3;  q3: S1 PPP = x1 a
+        opa.v[i] = bside ? (odd ? x1.v[i] : c.v[i]) : (odd ? d.v[i] : m2.v[i]);
+        opb.v[i] = bside ? (odd ? a.v[i] : m3.v[i]) : (odd ? t.v[i] : x2.v[i]);
+    }
+    const Fq30 m4 = fq30_mul(opa, opb);                                       // ZZ3 | R T | ZZZ3 | S1 PPP   < 1.04
+    // gather onto all four lanes
+    G1Xyzz out;
+    out.x = shfl_fq(x3, l1);
+    out.y = fq30_sub_lazy<2>(shfl_fq(m4, l1), shfl_fq(m4, l3));              // R T - S1 PPP   < 3.1
+    out.zz = shfl_fq(m4, l0);
+    out.zzz = shfl_fq(m4, l2);
+    if (__any(v_inf || o_inf || exc)) {
+        const G1Xyzz o = shfl_xor_point(v, mask);
+        if (exc) out = same ? g1_dbl(v) : G1Xyzz::inf();
+        else if (v_inf) out = o;
+        else if (o_inf) out = v;
+    }
+    return out;
+}
+// a whole butterfly over lanes [0, lanes) of a wavefront: the first step on lane pairs, the others on lane quadruples
+__device__ __forceinline__ G1Xyzz butterfly_reduce(G1Xyzz v, uint32_t lanes) {
+    if (lanes > 1) v = butterfly_add(v, 1);
+#pragma unroll 1
+    for (uint32_t mask = 2; mask < lanes; mask <<= 1) v = butterfly_add4(v, (int)mask);
+    return v;
+}
+
 }  // namespace ty

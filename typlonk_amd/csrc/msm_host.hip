@@ -113,11 +113,19 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         nch = ctx->msm_chunks ? (uint32_t)ctx->msm_chunks
                               : (m >= (1u << 20) ? (uint32_t)std::min<size_t>(m >> 19, MSM_MAX_CHUNKS) : 1u);
         while (nch > 1 && m / nch < 4096) --nch;
+    } else if (tables && m > ((size_t)1 << 20)) {
+        // A queued MSM (a batch, a prover round) of more than 2^20 terms: chunks of <= 2^20 terms one after the other on the
+        // MSM's own stream, all adding into the same buckets.  Not for overlap (the other lanes provide that) but for the
+        // sort's shape: above 2^20 terms a level-1 entry has too few bits left for the low bucket bits, the segment count
+        // passes 8192 and the sort falls back to the three-launch scan and the direct scatter (rounds 1-5: every
+        // commitment of a 2^22-row proof).
+        nch = (uint32_t)std::min<size_t>((m + ((size_t)1 << 20) - 1) >> 20, MSM_MAX_CHUNKS);
     }
     const size_t step = (m + nch - 1) / nch;
     hipStream_t s = ws.stream;
     int rc;
-    if (nch > 1) {
+    const bool overlap = nch > 1 && standalone;   // chunk k + 1 sorted on the side stream while chunk k accumulates
+    if (overlap) {
         // the side stream carries the sorts of the chunks after the first: short, latency-bound kernels beside an
         // accumulation that fills every wavefront slot (a high stream priority for it was measured: no effect)
         if (!ws.side) HIPCHK(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
@@ -139,11 +147,11 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         const Fr* sc = d_scalars + off;
         const uint32_t* pts = srs.d_points + off * PT_WORDS;  // chunk-local term index i -> base off + i (table t: + t*len)
         SortBufs& sb = ws.sb[k & 1];
-        hipStream_t ss = (nch > 1 && k > 0) ? ws.side : s;   // the first sort has nothing to overlap with
-        if (nch > 1 && k >= 2 && ss != s) HIPCHK(hipStreamWaitEvent(ss, ws.ev_acc[k - 2], 0));  // sb[k & 1] is free again
+        hipStream_t ss = (overlap && k > 0) ? ws.side : s;   // the first sort has nothing to overlap with
+        if (overlap && k >= 2) HIPCHK(hipStreamWaitEvent(ss, ws.ev_acc[k - 2], 0));  // sb[k & 1] is free again
         // the first chunk's sort is the exposed one: the second chunk's sort starts behind it (it then has the whole first
         // accumulation to hide under) instead of beside it, where it doubled its time (profiles/r03_msm_2_20_timeline.txt)
-        if (nch > 1 && k == 1) HIPCHK(hipStreamWaitEvent(ss, ws.ev_sorted[0], 0));
+        if (overlap && k == 1) HIPCHK(hipStreamWaitEvent(ss, ws.ev_sorted[0], 0));
         const uint64_t total = (uint64_t)W * mk;
         if ((rc = ensure(ctx, sb.keys, total * 4))) return rc;
         if ((rc = ensure(ctx, sb.sorted, total * 4))) return rc;
@@ -214,7 +222,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         if (ss != s) {   // an overlapped chunk: the accumulation on the MSM's stream waits for the side stream's sort
             HIPCHK(hipEventRecord(ws.ev_sorted[k], ss));
             HIPCHK(hipStreamWaitEvent(s, ws.ev_sorted[k], 0));
-        } else if (nch > 1 && k == 0) {
+        } else if (overlap && k == 0) {
             HIPCHK(hipEventRecord(ws.ev_sorted[0], s));
         }
         {
@@ -245,7 +253,7 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
                 ctx->accum_chain_live = true;
             }
         }
-        if (nch > 1 && k + 2 < nch) HIPCHK(hipEventRecord(ws.ev_acc[k], s));
+        if (overlap && k + 2 < nch) HIPCHK(hipEventRecord(ws.ev_acc[k], s));
     }
     // row/column bucket reduction (launch.hpp): c is in 8..20 and a plain MSM has at most 32 windows, so it always applies
     ws.rc = true;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void msm_fold_seq_kernel(FoldSeg a, FoldSeg b,
         v = ld_xyzz(g.in, base);
         for (uint32_t i = 1; i < (1u << g.lseq); ++i) v = g1_add(v, ld_xyzz(g.in, base + i));
     }
-    for (uint32_t mask = 1; mask < g.lanes; mask <<= 1) v = butterfly_add(v, (int)mask);
+    v = butterfly_reduce(v, g.lanes);
     if (t < g.threads && (t & (g.lanes - 1)) == 0) st_xyzz(g.out, t / g.lanes, v);
 }
 
@@ -136,8 +136,7 @@ __global__ __launch_bounds__(256) void msm_rc2_sums_kernel(const uint32_t* __res
         v = ld_xyzz(buckets, first);
         for (uint32_t i = 1; i < (1u << sc); ++i) v = g1_add(v, ld_xyzz(buckets, first + ((uint64_t)i << sh.cl)));
     }
-#pragma unroll 1
-    for (int mask = 1; mask < 64; mask <<= 1) v = butterfly_add(v, mask);
+    v = butterfly_reduce(v, 64);
     if (lane == 0) {
         if (wv < nwave_row) st_xyzz(prow, wv, v);
         else st_xyzz(pcol, wv - nwave_row, v);
@@ -177,8 +176,7 @@ __global__ __launch_bounds__(RC2_THREADS) void msm_rc2_planes_kernel(const uint3
             if ((rc_weight(sh, set, kind, item) >> bit) & 1u) v = g1_add(v, ld_xyzz(src, sbase + idx));
         }
     }
-#pragma unroll 1
-    for (int mask = 1; mask < 64; mask <<= 1) v = butterfly_add(v, mask);
+    v = butterfly_reduce(v, 64);
     const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll

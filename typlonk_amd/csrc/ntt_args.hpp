@@ -13,9 +13,6 @@ struct NttPassArgs {
     const Fr* in[NTT_BATCH_MAX];
     Fr* out[NTT_BATCH_MAX];
     uint32_t blocks_per_vec;
-    // the 9 x 30-bit kernel between its passes: elements (and the inter-pass twiddle table) as nine limbs, 36 bytes each, so
-    // that a pass neither re-cuts what the previous one wrote nor packs what the next one will re-cut (ntt_pass30_kernel)
-    uint32_t l9_in, l9_out, tw_l9;
     uint32_t k;        // log2 of this pass's sub-transform size M
     uint32_t logT;     // log2 of the tile width T
     uint32_t last;     // 1 for the final (contiguous, digit-reversing) pass

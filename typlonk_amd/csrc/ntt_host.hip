@@ -112,7 +112,7 @@ int get_pow_table30(typlonk_ctx* ctx, const std::string& key, const Fr& base, co
 // context like every other table.  Sizes above 2^NTT_FULL_MAX_LOG entries (2^24 = 512 MB) are not
 // built: *out stays empty and the kernel composes the factor from the two-level tables instead.
 int get_full_table(typlonk_ctx* ctx, const std::string& key, const Table& lo, const Table& hi, uint32_t h, uint64_t S,
-                   uint64_t n, Table* out, bool l9 = false) {
+                   uint64_t n, Table* out) {
     *out = Table{};
     if (n > (1ull << NTT_FULL_MAX_LOG)) return TYPLONK_OK;
     auto it = ctx->tables.find(key);
@@ -124,12 +124,12 @@ int get_full_table(typlonk_ctx* ctx, const std::string& key, const Table& lo, co
     Table t;
     t.n = n;
     t.last_use = ++ctx->table_tick;
-    hipError_t e = hipMalloc((void**)&t.d, n * (l9 ? 36 : sizeof(Fr)));
+    hipError_t e = hipMalloc((void**)&t.d, n * sizeof(Fr));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return TYPLONK_OK;  // no room: fall back to the two-level tables
     }
-    launch_ntt_full_table(lo.d, hi.d, h, S, n, t.d, l9, ctx->stream);
+    launch_ntt_full_table(lo.d, hi.d, h, S, n, t.d, ctx->stream);
     {
         DevGuard g;
         g.add(t.d);
@@ -277,12 +277,11 @@ int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t lo
     split_log(log_n, ks, &P, big);
     const std::string dir = inverse ? "i" : "f";
 
-    // (36 bytes per element: between its passes the 9 x 30-bit kernel keeps nine limbs per element, see `l9` below)
-    unsigned char* scratch = nullptr;
+    Fr* scratch = nullptr;
     if (P >= 2) {
-        int rc = ensure(ctx, ctx->ntt_scratch, count * N * 36);
+        int rc = ensure(ctx, ctx->ntt_scratch, count * N * sizeof(Fr));
         if (rc) return rc;
-        scratch = (unsigned char*)ctx->ntt_scratch.p;
+        scratch = (Fr*)ctx->ntt_scratch.p;
     }
 
     // measured (HISTORY.md section 5): the 9 x 30-bit kernel is 9-12 % faster up to 2^19; at 2^20 the two-pass 4096-element
@@ -329,12 +328,6 @@ int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t lo
 
     // The 9 x 30-bit kernel (fr30.hpp) multiplies with R' = 2^270: its tables carry an extra factor 2^14 and every one
     // of them must exist as a full table; if one cannot be built (size, memory) the transform runs on the 8 x 32 kernel.
-    // Round 6: BETWEEN its passes the 30-bit kernel keeps an element as its nine limbs (36 bytes in the scratch vector, the
-    // inter-pass twiddle table in the same form): the store of one pass and the load of the next used to pack into eight
-    // words and re-cut them -- ~280 of the 5150 VALU instructions a wavefront executes per pass of a 2^22 transform, for
-    // 12.5 % more bytes on a kernel that is VALU-bound.  The caller's vectors stay arkworks' 32-byte words.
-    // TYPLONK_NTT_L9=0: the packed form (A/B reference).
-    const bool l9 = ctx->ntt_l9;
     Table sub30[4]{}, tw30[4]{}, pre30{}, post30{}, scale30{};
     bool f30 = want30;
     for (uint32_t p = 0; p < P; ++p) f30 = f30 && ks[p] <= FR30_MAX_STAGES;   // the bounds of fr30.hpp hold for k <= 10
@@ -373,8 +366,8 @@ int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t lo
                 Table lo, hi;
                 uint32_t h = 0;
                 if ((rc = get_pow2l(ctx, "tw30:" + dir + ":" + std::to_string(lrow), wr, c14, lrow, &lo, &hi, &h))) return rc;
-                if ((rc = get_full_table(ctx, "tw30:" + dir + ":" + std::to_string(lrow) + ":full:" + std::to_string(k) + (l9 ? ":l9" : ""),
-                                         lo, hi, h, rl / M, rl, &tw30[p], l9)))
+                if ((rc = get_full_table(ctx, "tw30:" + dir + ":" + std::to_string(lrow) + ":full:" + std::to_string(k), lo, hi, h,
+                                         rl / M, rl, &tw30[p])))
                     return rc;
                 f30 = tw30[p].d != nullptr;
             }
@@ -445,7 +438,7 @@ int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t lo
         }
         for (size_t v = 0; v < count; ++v) {
             const Fr* src = short_in ? short_in[v] : d_data[v];
-            Fr* scr = scratch ? (Fr*)(scratch + v * N * (f30 && l9 ? 36 : sizeof(Fr))) : nullptr;
+            Fr* scr = scratch ? scratch + v * N : nullptr;
             a.in[v] = (p == 0) ? src : scr;
             a.out[v] = last ? d_data[v] : scr;
         }
@@ -461,9 +454,6 @@ int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t lo
             a.pre_full = p == 0 ? pre30.d : nullptr;
             a.post_full = last ? post30.d : nullptr;
             a.scale = last ? scale30.d : nullptr;
-            a.l9_in = (l9 && p > 0) ? 1u : 0u;
-            a.l9_out = (l9 && !last) ? 1u : 0u;
-            a.tw_l9 = l9 ? 1u : 0u;
         }
         // LDS: the tile, and (8 x 32 kernel) the sub-transform's twiddles behind it
         const size_t lds = f30 ? (size_t)E * 36 : (size_t)(E + std::max<uint64_t>(M / 2, 1)) * sizeof(Fr);

@@ -256,23 +256,6 @@ __device__ __forceinline__ void lds_st30(uint32_t* p, const Fr30& r) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) p[i] = r.v[i];
 }
-// nine limbs at a 4-byte-aligned address (two 16-byte accesses and one 4-byte access)
-struct __attribute__((packed, aligned(4))) NttL9 {
-    uint32_t w[9];
-};
-__device__ __forceinline__ Fr30 ntt_ld9(const Fr* base, uint64_t idx) {
-    const NttL9 v = reinterpret_cast<const NttL9*>(base)[idx];
-    Fr30 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.v[i] = v.w[i];
-    return r;
-}
-__device__ __forceinline__ void ntt_st9(Fr* base, uint64_t idx, const Fr30& x) {
-    NttL9 v;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) v.w[i] = x.v[i];
-    reinterpret_cast<NttL9*>(base)[idx] = v;
-}
 __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     const uint32_t NTT_THREADS = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
@@ -300,7 +283,6 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     auto gload = [&](uint32_t i, uint32_t t) -> Fr30 {
         const uint64_t g = a.last ? ((k1base + t) * a.Q + q) * M + i : base + (uint64_t)i * a.S + t;
         if (g >= a.n_valid) return fr30_unpack(Fr::zero());
-        if (a.l9_in) return ntt_ld9(vin, g);   // what the previous pass stored: exact limbs, < 2r, nothing to re-cut
         Fr30 x = fr30_unpack(ntt_ld(vin + g));
         if (a.pre_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.pre_full + g)));
         return x;
@@ -308,11 +290,8 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
     auto gstore = [&](uint32_t i, uint32_t t, Fr30 x) {   // the value at in-tile position i is output kk = bitrev_k(i)
         const uint32_t kk = (k ? (__brev(i) >> (32 - k)) : 0u);
         if (!a.last) {
-            const uint64_t ti = (uint64_t)kk * a.S + c0 + t;
-            x = fr30_mul(x, a.tw_l9 ? ntt_ld9(a.tw_full, ti) : fr30_unpack(ntt_ld(a.tw_full + ti)));
-            // < 2r with exact limbs: the next pass takes it as it is -- as nine limbs (36 B) or packed into eight words
-            if (a.l9_out) ntt_st9(vout, base + (uint64_t)kk * a.S + t, x);
-            else ntt_st(vout + (base + (uint64_t)kk * a.S + t), fr30_pack(x));
+            x = fr30_mul(x, fr30_unpack(ntt_ld(a.tw_full + ((uint64_t)kk * a.S + c0 + t))));
+            ntt_st(vout + (base + (uint64_t)kk * a.S + t), fr30_pack(x));  // < 2r: the next pass takes it as it is
         } else {
             const uint64_t o = obase + t + a.out_stride * kk;
             if (a.post_full) x = fr30_mul(x, fr30_unpack(ntt_ld(a.post_full + o)));
@@ -344,18 +323,15 @@ __global__ __launch_bounds__(1024) void ntt_pass30_kernel(NttPassArgs a) {
 }
 
 // out[idx] = lo/hi power at exponent (idx % S) * (idx / S) (S != 0: inter-pass twiddles) or idx (S == 0)
-// (l9: entries as nine 30-bit limbs on a 36-byte stride -- what ntt_pass30_kernel multiplies by without re-cutting)
 __global__ __launch_bounds__(256) void ntt_full_table_kernel(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n,
-                                                             Fr* out, uint32_t l9) {
+                                                             Fr* out) {
     const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     const uint64_t e = S ? (idx % S) * (idx / S) : idx;
-    const Fr w = ntt_pow2l(lo, hi, h, e);
-    if (l9) ntt_st9(out, idx, fr30_unpack(w));
-    else ntt_st(out + idx, w);
+    ntt_st(out + idx, ntt_pow2l(lo, hi, h, e));
 }
-void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n, Fr* out, bool l9, hipStream_t s) {
-    hipLaunchKernelGGL(ntt_full_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, h, S, n, out, l9 ? 1u : 0u);
+void launch_ntt_full_table(const Fr* lo, const Fr* hi, uint32_t h, uint64_t S, uint64_t n, Fr* out, hipStream_t s) {
+    hipLaunchKernelGGL(ntt_full_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, h, S, n, out);
 }
 
 // More than the default 64 KiB of dynamic LDS needs an opt-in (gfx950 has 160 KiB per workgroup).  The attribute is

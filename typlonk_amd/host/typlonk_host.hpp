@@ -188,6 +188,36 @@ inline DensePolynomial interpolate(const std::vector<Fr>& evals, const Radix2Eva
 inline std::vector<Fr> evaluate_over_domain(const DensePolynomial& p, const Radix2EvaluationDomain& d) {
     return d.fft(p.coeffs);
 }
+// A GROUP of interpolations -- the reference maps `interpolate` over the three wire columns (plonk/src/proof.rs:50), the five
+// selector columns (plonk/src/builder.rs:84-88), the three sigma columns (proof.rs:334-338): one upload, ONE
+// typlonk_ntt_fr_batch_devptr (every pass one launch for all columns), one download; ark-poly's trim per column.
+inline std::vector<DensePolynomial> interpolate_batch(const Context& ctx, const std::vector<std::vector<Fr>>& columns,
+                                                      const Radix2EvaluationDomain& d) {
+    const size_t count = columns.size(), n = d.size();
+    std::vector<DensePolynomial> out;
+    if (!count) return out;
+    typlonk_ctx* c = ctx.raw();
+    typlonk_buf* buf = nullptr;
+    check(typlonk_buf_alloc(c, n * count, &buf), c);
+    struct Free {
+        typlonk_ctx* c;
+        typlonk_buf* b;
+        ~Free() { typlonk_buf_free(c, b); }
+    } guard{c, buf};
+    std::vector<void*> ptrs(count);
+    for (size_t v = 0; v < count; ++v) {
+        if (columns[v].size() != n) throw std::runtime_error("every column must hold n evaluations");
+        check(typlonk_buf_upload(c, buf, v * n, columns[v][0].limbs(), n), c);
+        ptrs[v] = (char*)typlonk_buf_devptr(buf) + 32 * n * v;
+    }
+    check(typlonk_ntt_fr_batch_devptr(c, ptrs.data(), count, d.log_size_of_group(), 1, nullptr), c);
+    for (size_t v = 0; v < count; ++v) {
+        std::vector<Fr> co(n);
+        check(typlonk_buf_download(c, buf, v * n, co[0].limbs(), n), c);
+        out.push_back(DensePolynomial::from_coefficients_vec(std::move(co)));
+    }
+    return out;
+}
 
 }  // namespace poly
 
@@ -442,7 +472,15 @@ class CompiledCircuit {
             const std::vector<Fr>& ev = k < 5 ? selector_evals[k] : sigma_evals[k - 5];
             if (ev.size() != n_) throw std::runtime_error("circuit table must hold n evaluations");
             polys[k] = upload(ev);
-            check(typlonk_ntt_fr_dev(c, polys[k], 0, log_n, 1, nullptr), c);  // interpolate(), builder.rs:85
+        }
+        {   // interpolate(), builder.rs:84-88 and proof.rs:334-338: the eight columns as ONE batched inverse transform
+            void* ptrs[8];
+            for (int k = 0; k < 8; ++k) ptrs[k] = typlonk_buf_devptr(polys[k]);
+            const int rc = typlonk_ntt_fr_batch_devptr(c, ptrs, 8, log_n, 1, nullptr);
+            if (rc < 0) {
+                for (typlonk_buf* b : polys) typlonk_buf_free(c, b);
+                check(rc, c);
+            }
         }
         // the commitments of the fixed polynomials: [q_l] .. [q_c] (builder.rs:86) and [sigma_0..2], which the
         // reference's verifier recomputes with three MSMs on EVERY verify() (permutation/src/lib.rs:178-194 via
