@@ -59,4 +59,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 -- the launcher's summary buries a rank's traceback: one marked line for the test
+        print(f"WORKER_ERROR rank={os.environ.get('RANK')}: {type(e).__name__}: {e}", flush=True)
+        raise

@@ -549,6 +549,7 @@ __global__ __launch_bounds__(512) void msm_seg_scatter_staged_kernel(const Fr* s
 // Why: ~25 size bins are hot, adjacent words of ONE cache line, and every one of the 2048-4096 level-2 workgroups adds
 // to each of them -- 51 K atomics on one line, which the L2 retires one per clock: ~24 us per launch, the whole run time of
 // order_fused_kernel in rounds 1-5 and most of msm_seg_count / msm_seg_place.  Sixteen lines take them sixteen at a time.
+constexpr uint32_t MSM_PLACE_STAGE = 5120;   // entries of a segment msm_seg_place_kernel assembles in the LDS (20 KiB; mean 3328)
 constexpr uint32_t MSM_SCHED_REPLICAS = 16;
 constexpr uint32_t MSM_SCHED_WORDS = 1024 + 512 * MSM_SCHED_REPLICAS;
 uint32_t msm_sched_words() { return MSM_SCHED_WORDS; }
@@ -654,6 +655,11 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t h[256];      // this segment's buckets per size bin
     __shared__ uint32_t blk[256];    // where this segment's run inside each bin starts in order[]
+    // The segment's output, staged: an entry's place is data-dependent, so written straight to global memory every lane of
+    // a store instruction touches a different cache line -- 6.8 M four-byte requests per launch, the kernel's run time.
+    // The segment's slice of `sorted` is contiguous (~3300 entries), so it is assembled here and copied out in whole lines.
+    // A longer segment (adversarial scalars) writes directly.
+    __shared__ uint32_t seg_out[MSM_PLACE_STAGE];
     const uint32_t s = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
     const uint32_t start = seg_start[2 * s], end = seg_start[2 * s + 1];
     const uint32_t nlow = 1u << sh.lb;
@@ -682,6 +688,7 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
     // claim this segment's run inside every occupied bin (the answer is needed only after the placement loop)
     if (tid < 256) blk[k] = larger + before + (h[k] ? atomicAdd(&sched[1024 + 512 * rep + 256 + k], h[k]) : 0u);
     const uint32_t low_sh = sh.ibits + sh.jbits + 1;
+    const bool staged = end - start <= MSM_PLACE_STAGE;
     for (uint32_t e0 = start + tid; e0 < end; e0 += 8 * nt) {   // (eight loads in flight, as in the count kernel)
         uint32_t xs[8];
 #pragma unroll
@@ -695,11 +702,15 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
                 const uint32_t i = x & ((1u << sh.ibits) - 1);
                 const uint32_t j = (x >> sh.ibits) & ((1u << sh.jbits) - 1);
                 const uint32_t neg = (x >> (sh.ibits + sh.jbits)) & 1u;
-                sorted[start + pref[b] + r] = (j * sh.tlen + i) | (neg << 31);
+                const uint32_t val = (j * sh.tlen + i) | (neg << 31);
+                if (staged) seg_out[pref[b] + r] = val;
+                else sorted[start + pref[b] + r] = val;
             }
         }
     }
     __syncthreads();
+    if (staged)
+        for (uint32_t e = tid; e < end - start; e += nt) sorted[start + e] = seg_out[e];
     if (tid < nlow) order[blk[key] + rank] = bucket;
 }
 

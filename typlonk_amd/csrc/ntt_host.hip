@@ -246,9 +246,9 @@ int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t lo
         if (!d_data[v]) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null data");
     if (count == 0) return TYPLONK_OK;
     // vectors per launch: at most NTT_BATCH_MAX, and a multi-pass transform keeps one scratch vector per batch member
-    // (<= 2^26 elements = 2 GiB of scratch in all)
+    // (<= 2^25 elements = 1 GiB of scratch in all: the 2^24-point coset extensions of a 2^22-row proof go two at a time)
     size_t group = std::min<size_t>(count, NTT_BATCH_MAX);
-    while (group > 1 && (((uint64_t)group) << log_n) > (1ull << 26)) --group;
+    while (group > 1 && (((uint64_t)group) << log_n) > (1ull << 25)) --group;
     if (count > group) {
         int rc = TYPLONK_OK;
         for (size_t g0 = 0; g0 < count && !rc; g0 += group)

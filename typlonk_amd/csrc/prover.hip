@@ -435,7 +435,7 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     };
     MsmQueue q(ctx, srs, /*first_lane=*/1);
     p->has_pi = pi_evals != nullptr;  // NULL: public inputs [0] -> the zero polynomial
-    if (ctx->prover_ntt_batch) {
+    if (ctx->prover_ntt_batch == 1 || ctx->prover_ntt_batch == 2) {
         // mode 1: the three interpolations (and the public-input column's, proof.rs:105-106) as ONE batched transform
         // (ntt_run_batch), then the three commitments; mode 2: the first column alone -- its commitment starts at once --
         // and the others as one batch beside it.  Either way the coset extensions of the group are one batch.
@@ -470,8 +470,14 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
         }
         // the coset transforms of the quotient's per-proof inputs run beside the commitments (measured: -1 % per proof;
         // submitting round 3's first opening MSMs before the quotient loses 1 %: profiles/r02_ab_prover_overlap.txt)
-        for (int i = 0; i < 3 && !rc; ++i) rc = prover_extend(p, i, p->co[i]);
-        if (!rc && p->has_pi) rc = prover_extend(p, 4, p->pi);
+        if (ctx->prover_ntt_batch == 3) {   // mode 3: interpolations one by one (above), the extensions as one batch
+            Fr* grp[4] = {p->co[0], p->co[1], p->co[2], p->pi};
+            const int slots[4] = {0, 1, 2, 4};
+            if (!rc) rc = prover_extend_batch(p, slots, grp, p->has_pi ? 4 : 3);
+        } else {
+            for (int i = 0; i < 3 && !rc; ++i) rc = prover_extend(p, i, p->co[i]);
+            if (!rc && p->has_pi) rc = prover_extend(p, 4, p->pi);
+        }
     }
     {
         const int r = q.wait_all();
