@@ -61,6 +61,15 @@ def _isa(name: str, key: str, default):
         return default
 
 
+def _sq(kind: str, key: str) -> dict:
+    """SQ-counter summary of a kernel from the newest committed profiles/r0x_pmc_sq_valu_<kind>.json that has it"""
+    for rnd in ("r06", "r05"):
+        d = _isa(f"{rnd}_pmc_sq_valu_{kind}.json", key, None)
+        if d:
+            return dict(d, source=f"profiles/{rnd}_pmc_sq_valu_{kind}.json")
+    return {}
+
+
 MIXED_ADD_MULTIPLIER_CEILING = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_multiplier_only", 11.956e9))
 MIXED_ADD_ALL_VALU_MODEL = float(_isa("r04_isa_msm_accum.json", "ceiling_units_per_s_all_valu", 8.398e9))
 # the same for one Fr multiplication inside the NTT butterflies.  Since round 4 the default kernel is the one on nine 30-bit
@@ -541,9 +550,9 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
                     "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, "
                                       "bytes per launch)"},
             "hbm_frac": ach / HBM_PEAK_GBS,
-            "sq_valu_util": _isa("r05_pmc_sq_valu_msm.json", "ty::msm_accum_kernel grid=524288", {}).get("valu_util"),
-            "effective_clock_ghz": _isa("r05_pmc_sq_valu_msm.json", "ty::msm_accum_kernel grid=524288", {}).get("effective_clock_ghz"),
-            "note": "integer-VALU-bound (92 % of the issue slots at an effective 2.2 GHz, profiles/r05_pmc_sq_valu_msm.json); the HBM "
+            "sq_valu_util": _sq("msm", "ty::msm_accum_kernel grid=524288").get("valu_util"),
+            "effective_clock_ghz": _sq("msm", "ty::msm_accum_kernel grid=524288").get("effective_clock_ghz"),
+            "note": "integer-VALU-bound (92 % of the issue slots at an effective 2.2 GHz, profiles/r0x_pmc_sq_valu_msm.json); the HBM "
                     "fraction the north-star asks for is kept as hbm_frac; PMC traffic is "
                     + (f"{traffic / alg_bytes:.1f}" if traffic else "~19.5") + " x the algorithmic bytes (13 window gathers of a "
                     "128-B-stride record each + bucket store / reload, served by the Infinity Cache) -- see DESIGN.md section 4"}
@@ -621,7 +630,7 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
                               "all_valu_model": {"peak": FR_MUL_ALL_VALU_MODEL, "frac": fr_muls / kern_s / FR_MUL_ALL_VALU_MODEL,
                                                  "note": "all 1155 VALU instructions of a radix-4 group (4 multiplications, 8 lazy "
                                                          "additions / subtractions, addressing) priced by class: 4156 cycles"},
-                              "sq_valu_util": _isa("r05_pmc_sq_valu_ntt.json", "ty::ntt_pass30_kernel grid=%d" % (n // 4), {}).get("valu_util")}}
+                              "sq_valu_util": _sq("ntt", "ty::ntt_pass30_kernel grid=%d" % (n // 4)).get("valu_util")}}
     # the same transform in a GROUP of three (typlonk_ntt_fr_batch_devptr: every pass one launch carrying three vectors' tiles)
     # -- how the reference issues its interpolations (proof.rs:50, 113-115, 334-338) and how round 1 of typlonk_prove does
     try:
@@ -645,7 +654,8 @@ def bench_ntt(ctx, n, log_n, device, result) -> None:
     except Exception as e:  # noqa: BLE001 -- a secondary figure
         result["ntt"]["batched_error"] = f"{type(e).__name__}: {e}"
     # PMC traffic of one pass (the 30-bit kernel since round 4; the older files describe the 8 x 32 kernel)
-    for name, key in (("r05_pmc_ntt.json", f"ntt_pass30_kernel n=2^{log_n}"), ("r03_pmc_ntt.json", f"ntt_pass_kernel n=2^{log_n}")):
+    for name, key in (("r06_pmc_ntt.json", f"ntt_pass30_kernel n=2^{log_n}"), ("r05_pmc_ntt.json", f"ntt_pass30_kernel n=2^{log_n}"),
+                      ("r03_pmc_ntt.json", f"ntt_pass_kernel n=2^{log_n}")):
         pm = _isa(name, key, None)
         if pm:
             result["ntt"]["pmc_traffic_bytes_per_pass"] = pm["traffic_bytes_per_pass"]

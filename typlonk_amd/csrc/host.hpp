@@ -127,8 +127,9 @@ struct typlonk_buf {
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
 //   TYPLONK_NTT_FR30      0 | 1 | 2: the 9 x 30-bit butterflies never / where they measure faster / always
 //   TYPLONK_NTT_BIG       0 | 1 | 2: the two-pass 2^20 plan (4096-element tiles) never / where it measures faster / always
-//   TYPLONK_PROVER_NTT_BATCH 0 | 1 | 2: round 1 transforms its columns one by one (each commitment submitted as soon as its
-//                         polynomial exists) / as one batched transform per group (ntt_run_batch) / the first alone, the rest batched
+//   TYPLONK_PROVER_NTT_BATCH 0 | 1 | 2 | 3: round 1 transforms its columns one by one (each commitment submitted as soon as its
+//                         polynomial exists) / as one batched transform per group (ntt_run_batch) / the first alone, the rest
+//                         batched / interpolations one by one, coset extensions batched
 //   TYPLONK_PROVER_PIPE   0 | 1: round 3's nine commitments queued as in rounds 1-4 / behind one fence (prover_round3_core)
 // (TYPLONK_RCCL_LIB, read by comm.hip, names the RCCL library to load.)
 struct typlonk_ctx {
@@ -165,8 +166,13 @@ struct typlonk_ctx {
     // 0.419 -> 0.464 ms per MSM -- so the switch sits below the shard size; from 2^19 on the chain is never worse and
     // 2^20 needs it.  -1 = by term count (MSM_CHAIN_MIN_TERMS), 0 / 1 = TYPLONK_MSM_CHAIN.
     int msm_chain = -1;
-    int prover_ntt_batch = 2;      // TYPLONK_PROVER_NTT_BATCH: round 1's interpolations / coset extensions 0 = one by one, 1 = one batch
-                                   // per group, 2 = the first column alone (its commitment starts at once), the rest batched
+    int prover_ntt_batch = 0;      // TYPLONK_PROVER_NTT_BATCH: round 1's interpolations / coset extensions 0 = one by one (each commitment
+                                   // submitted as soon as its polynomial exists), 1 = one batched transform per group, 2 = the first
+                                   // column alone, the rest batched, 3 = interpolations one by one, extensions batched.  Measured
+                                   // (profiles/r06_ab_prover_ntt_batch.txt): inside a proof the batched forms LOSE 0.3-0.5 ms at 2^20 --
+                                   // they delay a commitment's start by the other columns' transforms, and the transforms were
+                                   // already hidden beside the commitments' sorts; the batched entry point pays where nothing
+                                   // runs beside it (typlonk_circuit_load, a caller's interpolate groups)
     bool prover_pipe = true;       // TYPLONK_PROVER_PIPE (A/B switch of the round-5 queueing fix, prover_round3_core)
     int msm_chunks = 0;            // chunks of a stand-alone MSM (0 = choose by length)
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
