@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 6, call I: MSMs in flight per batch (TYPLONK_MSM_INFLIGHT 3..6) now that sorts are cheap
+export TMPDIR=/tmp
+O=gpurun_out/r6i; mkdir -p $O
+for rep in 1 2 3; do for v in 3 4 5 6; do echo "== INFLIGHT=$v rep $rep"; TYPLONK_MSM_INFLIGHT=$v REPS=10 python3 tools/msm_batch_loop.py 2>/dev/null | tail -1; done; done > $O/batch_ab.txt 2>&1; cat $O/batch_ab.txt
+for rep in 1 2 3; do for v in 3 4 5 6; do echo "== prove INFLIGHT=$v rep $rep"; TYPLONK_MSM_INFLIGHT=$v python3 tools/prove_rounds.py 2>/dev/null | tail -2; done; done > $O/prove_ab.txt 2>&1; cat $O/prove_ab.txt
+for v in 3 5; do echo "== 2^22 prove INFLIGHT=$v"; LOG_N=22 TYPLONK_MSM_INFLIGHT=$v python3 tools/prove_rounds.py 2>/dev/null | tail -2; done > $O/prove_ab_22.txt 2>&1; cat $O/prove_ab_22.txt
+TYPLONK_MSM_INFLIGHT=5 REPS=3 BATCH=9 rocprofv3 --kernel-trace --output-format csv -d $O/batch_trace -- python3 tools/msm_batch_loop.py > $O/batch_loop.log 2>&1
+python3 tools/trace_timeline.py $(find $O/batch_trace -name "*kernel_trace.csv" | head -1) > $O/msm_batch_timeline_5.txt 2>&1; grep -n "accum\|span" $O/msm_batch_timeline_5.txt
+find $O -name "*kernel_trace.csv" -size +4M -delete

@@ -147,11 +147,11 @@ struct typlonk_ctx {
     tyh::DevBuf scal;
     static constexpr int MSM_LANES = 4;
     tyh::MsmWs ws[MSM_LANES];
-    hipStream_t lane[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // lanes 1.. of typlonk_msm_g1_batch* (lane 0 = stream)
+    hipStream_t lane[MSM_LANES] = {};  // lanes 1.. of typlonk_msm_g1_batch* (lane 0 = stream)
     int msm_inflight = 0;           // MSMs of a batch in flight at once (1..MSM_LANES; 0 = by SRS length: 3, where the
                                     // accumulations are chained and a fourth lane only adds a sort competing for the same
                                     // slots (profiles/r03_msm_chain_ab.txt), 4 below 2^17 points, where they run free)
-    hipEvent_t lane_evt[MSM_LANES] = {nullptr, nullptr, nullptr, nullptr};  // "scalars ready" marks (MsmQueue::submit)
+    hipEvent_t lane_evt[MSM_LANES] = {};  // "scalars ready" marks (MsmQueue::submit)
     hipEvent_t batch_fence = nullptr;   // typlonk_msm_g1_batch_devptr: everything queued before the call (MsmQueue::fence)
     // Queued MSMs (a batch, a prover round) run their accumulations ONE AFTER THE OTHER, whichever lanes they are on: the
     // kernel fills every SIMD by itself, so two of them side by side only take turns -- while the sort of the next MSM
