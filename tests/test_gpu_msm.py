@@ -557,6 +557,71 @@ def test_chunked_pipeline_gives_identical_results(built, chunks, monkeypatch):
         c2.close()
 
 
+@pytest.mark.parametrize("scatter,l1", [("staged", "512"), ("staged", "256"), ("direct", "512")])
+def test_every_form_of_the_bucket_sort_gives_the_same_point(built, scatter, l1, monkeypatch):
+    """Round 6 rebuilt the bucket sort: level 1 stages its runs in the LDS (TYPLONK_MSM_SCATTER=direct keeps the rounds 1-5 form,
+    also the fallback for shapes whose staging area does not fit), 256 or 512 threads per level-1 workgroup, level 2 assembles
+    a segment's output in the LDS unless the segment is longer than its staging array.  Every form, at the table-mode sizes
+    the prover uses -- 2^19 + 5 terms (a chunk: 2048 segments), 2^20 - 3 (a queued MSM: 4096 segments), 2^20 + 2^19 + 1 (three
+    chunks), an 8-way shard's 2^17 (c = 17) -- must give commit(p) == [p(s)]G (kzg/src/lib.rs:102-105), for uniform scalars
+    and for the sets that overflow a segment: all scalars equal (ONE bucket per window takes everything: a segment of 2^20
+    entries, far beyond the level-2 staging array, and heavy-bucket tasks), two values, tiny scalars, alternating 0 / r - 1."""
+    import typlonk_amd
+    from oracle import coracle as CO
+
+    monkeypatch.setenv("TYPLONK_MSM_SCATTER", scatter)
+    monkeypatch.setenv("TYPLONK_MSM_L1_THREADS", l1)
+    c2 = typlonk_amd.Context(0)
+    try:
+        length = (1 << 20) + (1 << 19) + 4
+        s_limbs = np.array(O.fr_to_mont_limbs(0x1357_9BDF_2468), dtype=np.uint64)
+        tab = c2.srs_generate(s_limbs, length)
+        c2.srs_precompute(tab, 20)
+        small = c2.srs_generate(s_limbs, (1 << 17) + 9)
+        c2.srs_precompute(small, 0)                                   # the library's choice for a shard: c = 17
+        rng = np.random.default_rng(int(l1) + len(scatter))
+        rep = [np.array(O.fr_to_mont_limbs(v), dtype=np.uint64) for v in O.random_frs(99, 2)]
+        rm1 = np.array(O.fr_to_mont_limbs(O.R - 1), dtype=np.uint64)
+
+        def scalars(kind, m):
+            if kind == "uniform":
+                sc = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2
+                sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+                return sc
+            if kind == "equal":
+                return np.tile(rep[0], (m, 1))
+            if kind == "two_values":
+                sc = np.tile(rep[0], (m, 1))
+                sc[1::2] = rep[1]
+                return sc
+            if kind == "tiny":
+                sc = np.zeros((m, 4), dtype=np.uint64)
+                small_vals = {v: np.array(O.fr_to_mont_limbs(v), dtype=np.uint64) for v in range(16)}
+                for v in range(16):
+                    sc[v::16] = small_vals[v]
+                return sc
+            sc = np.zeros((m, 4), dtype=np.uint64)                    # alternating 0 / r - 1
+            sc[0::2] = rm1
+            return sc
+
+        cases = [(tab, (1 << 19) + 5, ("uniform", "equal", "tiny")), (tab, (1 << 20) - 3, ("uniform", "two_values", "alternating")),
+                 (tab, length - 3, ("uniform", "equal")), (small, 1 << 17, ("uniform", "equal", "alternating"))]
+        for sid, m, kinds in cases:
+            for kind in kinds:
+                sc = scalars(kind, m)
+                exp_xy, exp_inf = CO.g1_mul_generator(CO.poly_eval(sc, s_limbs))
+                got, ginf = c2.msm(sid, sc)
+                assert (got == exp_xy).all() and ginf == exp_inf, (scatter, l1, m, kind)
+                if m <= (1 << 20) and kind != "tiny":                  # the same MSM queued (batch form: one launch, 4096 segments)
+                    buf = c2.alloc(m)
+                    buf.upload(sc)
+                    outs = c2.msm_batch_devptr(sid, [buf.devptr, buf.devptr], [m, m - 1])
+                    assert (np.asarray(outs[0][0]) == exp_xy).all() and outs[0][1] == exp_inf, (scatter, l1, m, kind, "queued")
+                    buf.free()
+    finally:
+        c2.close()
+
+
 @pytest.mark.slow
 def test_more_than_2_23_terms_takes_the_counting_sort_fallback(ctx):
     """The segmented sort indexes terms with 23 bits; a longer MSM falls back to the global counting sort (msm_host.hip
