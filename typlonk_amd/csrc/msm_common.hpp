@@ -1,20 +1,21 @@
 // Pippenger bucket MSM over BLS12-381 G1 (replaces the per-term double-and-add of
 // KzgScheme::evaluate_in_s, /root/reference/kzg/src/lib.rs:41-54).
 //
-//   1. msm_digits_kernel   one thread per scalar: Montgomery -> canonical (ark-ff into_repr, the
-//                          conversion lib.rs:49 performs per term), signed c-bit window slicing,
-//                          one key per (window, scalar) + bucket histogram.
-//   2. scan kernels        exclusive prefix sum of the histogram -> bucket offsets.
-//   3. msm_scatter_kernel  counting sort of (point index, sign) by bucket.
-//   4. msm_accum_kernel    one thread per bucket: XYZZ accumulator in registers, mixed additions of
-//                          the bucket's affine points gathered from the resident SRS.
-//   5. msm_rc_* kernels    per bucket set sum_k w(k)*B_k by the row/column split (launch.hpp): plain row
-//                          and column sums, then bit planes of the R + C weighted sums via wavefront
-//                          __shfl_xor butterflies of whole points.  (msm_reduce_kernel / msm_fold_kernel:
-//                          the first version, running sums + a small scalar multiplication per thread.)
+//   1. sort (msm_sort.hip)     the (window, term) pairs by bucket.  Table mode and every shape up to 2^23 terms: the
+//                              SEGMENTED counting sort -- msm_seg_hist / msm_seg_prefix / msm_seg_scatter_staged (level 1:
+//                              Montgomery -> canonical, ark-ff into_repr, the conversion lib.rs:49 performs per term; signed
+//                              c-bit window slicing; entries partitioned into segments of <= 256 buckets through the LDS, no
+//                              global atomics), msm_seg_count / msm_seg_place (level 2: one workgroup per segment; bucket
+//                              counts, offsets, the final (point index, sign) list AND the bucket schedule order[]).
+//                              Beyond that: msm_digits_kernel + scan + msm_scatter_kernel (global atomics) + order_* kernels.
+//   2. msm_accum_kernel        one thread per bucket in population order: XYZZ accumulator in registers, mixed additions
+//                              of the bucket's affine points gathered from the resident SRS (msm_accum.hip).
+//   3. msm_rc_* kernels        per bucket set sum_k w(k)*B_k by the row/column split (launch.hpp): plain row and column
+//                              sums, then bit planes of the R + C weighted sums via wavefront __shfl butterflies of whole
+//                              points (msm_reduce.hip).
 // The W window sums go to the host, which applies the 2^(c*j) weights (Horner) and normalises
 // to the canonical affine point.  Group addition is commutative and the result is canonical, so
-// the non-deterministic order inside a bucket (atomics in step 3) cannot change the output.
+// the non-deterministic order inside a bucket (the atomics of the sort) cannot change the output.
 #pragma once
 #include "g1.hpp"
 #include "launch.hpp"

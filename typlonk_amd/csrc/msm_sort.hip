@@ -1,5 +1,7 @@
-// MSM staging kernels: infinity marking, scalar -> signed window digits + histogram, exclusive scan,
-// counting-sort scatter.  See msm_common.hpp for the overall MSM structure.
+// MSM staging kernels: SRS conversion, and the bucket sort of the (window, term) pairs -- the two-level segmented
+// counting sort every table-mode MSM takes (level 1 through the LDS, level 2 one workgroup per segment, bucket schedule
+// included; rebuilt in round 6, profiles/r06_ab_sort.txt) and the atomic counting sort kept for shapes it cannot take.
+// See msm_common.hpp for the overall MSM structure.
 #include "launch.hpp"
 #include <algorithm>
 #include "msm_common.hpp"

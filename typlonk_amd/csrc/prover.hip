@@ -143,10 +143,20 @@ int quotient_run(typlonk_ctx* ctx, const typlonk_quotient_args* args, uint32_t l
     const uint64_t* g_limbs = quotient_coset_g(&g);
     ProfilingOff prof_off(ctx);  // stage events are per call
     const Fr ninv = fe_inv(fr_from_u64(n));
-    for (int k = 0; k < (cached ? 5 : 14) && !rc; ++k) {
-        if (k == 4 && !has_pi) continue;
-        if (k < 5 && ((extended >> k) & 1u)) continue;
-        rc = quotient_extend(ctx, ext + (uint64_t)k * n4, k < 13 ? in[k]->d : nullptr, &ninv, n, log4);
+    {
+        // every input that is not extended yet, as batched coset transforms (one launch per pass and group, ntt_run_batch);
+        // L0 (k = 13, a constant-coefficient polynomial) is built in place
+        Fr* dst[13];
+        const Fr* src[13];
+        size_t cnt = 0;
+        for (int k = 0; k < (cached ? 5 : 13); ++k) {
+            if (k == 4 && !has_pi) continue;
+            if (k < 5 && ((extended >> k) & 1u)) continue;
+            dst[cnt] = ext + (uint64_t)k * n4;
+            src[cnt++] = in[k]->d;
+        }
+        if (cnt) rc = quotient_extend_batch(ctx, dst, src, cnt, n, log4);
+        if (!rc && !cached) rc = quotient_extend(ctx, ext + (uint64_t)13 * n4, nullptr, &ninv, n, log4);
     }
     if (rc) {
         return rc;
