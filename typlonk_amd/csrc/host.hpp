@@ -312,8 +312,9 @@ void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf);
 int msm_validate(typlonk_ctx* ctx, uint32_t srs_id, size_t m, const SrsEntry** srs);
 // d_scalars points at coefficient 0 of the m-term vector (ptr_is_local: at the first coefficient of this
 // entry's share instead); an SRS shard sums only its own index range
+// h_scalars != NULL (with ptr_is_local): the local share still lives on the host and is copied chunk by chunk beside the kernels
 int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12], uint8_t* out_inf,
-            bool ptr_is_local = false);
+            bool ptr_is_local = false, const uint64_t* h_scalars = nullptr);
 // count independent MSMs over the same SRS, up to MSM_LANES in flight (separate workspaces/streams)
 int msm_batch(typlonk_ctx* ctx, uint32_t srs_id, const void* const* d_scalars, const size_t* m, size_t count, uint64_t* out_xy,
               uint8_t* out_inf);

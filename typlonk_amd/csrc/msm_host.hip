@@ -70,8 +70,11 @@ void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf) 
 
 // Launch every kernel of one m-term MSM (m > 0, validated by the caller) on `stream` using workspace
 // `ws`, ending with the asynchronous copy of the W window sums into ws.host_wins.
+// h_scalars != NULL: the scalars are still on the HOST (typlonk_msm_g1: the reference's commit() hands over a Vec<Fr>); every
+// chunk's slice is copied to d_scalars on the stream that sorts that chunk, so the copy of chunk k + 1 crosses PCIe while chunk k
+// is sorted and accumulated instead of the whole vector crossing before the first kernel starts.
 int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry& srs, const Fr* d_scalars, size_t m,
-                uint64_t* out_xy, uint8_t* out_inf, bool standalone) {
+                uint64_t* out_xy, uint8_t* out_inf, bool standalone, const uint64_t* h_scalars) {
     ws.stream = stream;
     if (!ws.host_wins) HIPCHK(hipHostMalloc((void**)&ws.host_wins, HOST_WIN_POINTS * 192));
     uint32_t c, W;
@@ -152,6 +155,8 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         // the first chunk's sort is the exposed one: the second chunk's sort starts behind it (it then has the whole first
         // accumulation to hide under) instead of beside it, where it doubled its time (profiles/r03_msm_2_20_timeline.txt)
         if (overlap && k == 1) HIPCHK(hipStreamWaitEvent(ss, ws.ev_sorted[0], 0));
+        if (h_scalars)
+            HIPCHK(hipMemcpyAsync(const_cast<Fr*>(sc), h_scalars + 4 * off, mk * sizeof(Fr), hipMemcpyHostToDevice, ss));
         const uint64_t total = (uint64_t)W * mk;
         if ((rc = ensure(ctx, sb.keys, total * 4))) return rc;
         if ((rc = ensure(ctx, sb.sorted, total * 4))) return rc;
@@ -361,7 +366,8 @@ int msm_validate(typlonk_ctx* ctx, uint32_t srs_id, size_t m, const SrsEntry** s
 
 // d_scalars points at coefficient 0 of the m-term vector (ptr_is_local: at the first coefficient of this
 // entry's share instead); an SRS shard sums only its own index range
-int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12], uint8_t* out_inf, bool ptr_is_local) {
+int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, uint64_t out_xy[12], uint8_t* out_inf, bool ptr_is_local,
+            const uint64_t* h_scalars) {
     if (!out_xy || !out_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null output");
     const SrsEntry* srs = nullptr;
     int rc = msm_validate(ctx, srs_id, m, &srs);
@@ -377,7 +383,7 @@ int msm_run(typlonk_ctx* ctx, uint32_t srs_id, const Fr* d_scalars, size_t m, ui
     if (!d_scalars) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null scalars");
     if (!ptr_is_local) d_scalars += off;
     m = ml;
-    if ((rc = msm_enqueue(ctx, ctx->ws[0], ctx->stream, *srs, d_scalars, m, out_xy, out_inf, /*standalone=*/true))) return rc;
+    if ((rc = msm_enqueue(ctx, ctx->ws[0], ctx->stream, *srs, d_scalars, m, out_xy, out_inf, /*standalone=*/true, h_scalars))) return rc;
     if ((rc = msm_finish(ctx, ctx->ws[0]))) return rc;
     prof_collect(ctx);
     return TYPLONK_OK;
@@ -418,7 +424,7 @@ int MsmQueue::submit(const Fr* d_scalars, size_t m, uint64_t* out_xy, uint8_t* o
         }
         st = ctx->lane[l];
     }
-    return msm_enqueue(ctx, ws, st, *srs, d_scalars + off, ml, out_xy, out_inf, standalone);
+    return msm_enqueue(ctx, ws, st, *srs, d_scalars + off, ml, out_xy, out_inf, standalone, nullptr);
 }
 int MsmQueue::wait_all() {
     int rc = TYPLONK_OK;
@@ -670,12 +676,11 @@ int typlonk_msm_g1(typlonk_ctx* ctx, uint32_t srs_id, const uint64_t* scalars, s
     if (m > it->second.total()) return fail(ctx, TYPLONK_ERR_LENGTH, "MSM length exceeds SRS length (kzg/src/lib.rs:43)");
     size_t off, ml;
     it->second.local_range(m, &off, &ml);
-    if (ml) {  // only this entry's share of the coefficients crosses PCIe
+    if (ml) {  // only this entry's share of the coefficients crosses PCIe -- chunk by chunk, beside the kernels (msm_enqueue)
         int rc = ensure(ctx, ctx->scal, ml * sizeof(Fr));
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->scal.p, scalars + 4 * off, ml * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     }
-    return msm_run(ctx, srs_id, (const Fr*)ctx->scal.p, m, out_xy, out_inf, /*ptr_is_local=*/true);
+    return msm_run(ctx, srs_id, (const Fr*)ctx->scal.p, m, out_xy, out_inf, /*ptr_is_local=*/true, ml ? scalars + 4 * off : nullptr);
 }
 
 int typlonk_g1_sum_host(const uint64_t* xy, const uint8_t* inf, size_t count, uint64_t out_xy[12], uint8_t* out_inf) {
