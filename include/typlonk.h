@@ -309,6 +309,13 @@ typedef struct typlonk_proof {
 } typlonk_proof;
 int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
                   const typlonk_buf* pi_evals, const uint64_t cosets[3][4], typlonk_proof* out);
+/* The same with the columns still in HOST memory -- how the reference holds them when prove() starts (the padded, blinded
+ * Vec<Fr> columns of plonk/src/proof.rs:43-49 and the padded public inputs :52-53): wire_evals[i] and pi_evals (NULL = the zero
+ * polynomial) point at n = 2^log_n Fr elements each, 4 limbs per element.  Each column is copied to the device right before its
+ * interpolation and commitment are queued, so column i + 1 crosses PCIe while column i is transformed, sorted and accumulated
+ * (128 MiB of uploads at 2^20 that a caller of typlonk_prove pays before the first kernel starts).  Same proof, bit for bit. */
+int typlonk_prove_host(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const uint64_t* const wire_evals[3],
+                       const uint64_t* pi_evals, const uint64_t cosets[3][4], typlonk_proof* out);
 /* The transcript alone (host-only, no GPU): digest `count` commitments (C-ABI form) in order and squeeze
  * n_challenges Fr elements (4 Montgomery limbs each) -- ChallengeGenerator::with_digest(..).generate_challenges::<N>(). */
 int typlonk_transcript_challenges(const uint64_t* xy, const uint8_t* inf, size_t count, size_t n_challenges, uint64_t* out);

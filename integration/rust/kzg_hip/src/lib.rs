@@ -283,15 +283,22 @@ impl Backend {
     /// Panics with "r(zeta) != 0" where the reference panics in `vanishes()` (:321, :361).
     pub fn prove(&self, srs: SrsHandle, circuit: CircuitHandle, wire_evals: [&[Fr]; 3], public_inputs: &[Fr],
                  cosets: [Fr; 3]) -> ffi::TyplonkProof {
+        // The columns go over as they are, in host memory (`typlonk_prove_host`, round 6): the library uploads each one right
+        // before its interpolation and commitment are queued, so column i + 1 crosses PCIe while column i is transformed,
+        // sorted and accumulated -- instead of four uploads (128 MiB at 2^20) before the first kernel starts.
         let n = 1usize << circuit.log_n;
-        let w: Vec<DeviceVec> = wire_evals.iter().map(|c| self.upload(c, n)).collect();
-        let wp: Vec<*const ffi::TyplonkBuf> = w.iter().map(|d| d.buf as *const _).collect();
-        let pi = if public_inputs.iter().all(|x| x.is_zero()) { None } else { Some(self.upload(public_inputs, n)) };
+        let flat = |c: &[Fr]| -> Vec<u64> {
+            assert_eq!(c.len(), n);
+            c.iter().flat_map(|e| fr_limbs(e)).collect()
+        };
+        let w: Vec<Vec<u64>> = wire_evals.iter().map(|c| flat(c)).collect();
+        let wp: [*const u64; 3] = [w[0].as_ptr(), w[1].as_ptr(), w[2].as_ptr()];
+        let pi = if public_inputs.iter().all(|x| x.is_zero()) { None } else { Some(flat(public_inputs)) };
         let k = [fr_limbs(&cosets[0]), fr_limbs(&cosets[1]), fr_limbs(&cosets[2])];
         let mut out = std::mem::MaybeUninit::<ffi::TyplonkProof>::zeroed();
         self.check(unsafe {
-            ffi::typlonk_prove(self.ctx, srs.id, circuit.id, wp.as_ptr(),
-                               pi.as_ref().map_or(ptr::null(), |d| d.buf as *const _), k.as_ptr(), out.as_mut_ptr())
+            ffi::typlonk_prove_host(self.ctx, srs.id, circuit.id, wp.as_ptr(), pi.as_ref().map_or(ptr::null(), |v| v.as_ptr()),
+                                    k.as_ptr(), out.as_mut_ptr())
         });
         unsafe { out.assume_init() }
     }

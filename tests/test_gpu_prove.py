@@ -390,6 +390,49 @@ def test_native_prove_equals_the_round_by_round_flow(ctx, log_n):
     ctx.srs_free(sid)
 
 
+@pytest.mark.parametrize("log_n,tables", [(4, False), (10, False), (16, True)])
+def test_prove_from_host_columns_equals_prove_from_device_buffers(ctx, log_n, tables):
+    """typlonk_prove_host: the padded, blinded columns handed over in HOST memory -- how the reference holds them when
+    prove() starts (plonk/src/proof.rs:43-53) and what the Rust layer's Backend::prove now passes -- uploaded column by column
+    beside round 1's kernels.  Same proof as typlonk_prove on device buffers, element for element, with and without a
+    public-input column; a null column is refused."""
+    from typlonk_amd.capi import ERR_INVALID_ARG, TyplonkError
+    from typlonk_amd.circuits import SquaringChain
+
+    n = 1 << log_n
+    sid = ctx.srs_generate(_limbs(0xBEEF5), n + 3)
+    if tables:
+        ctx.srs_precompute(sid, 0)
+    chain = SquaringChain(ctx, log_n)
+    try:
+        host_w = [b.download() for b in chain.wire_evals]
+        host_pi = np.zeros((n, 4), dtype=np.uint64)          # the circuit's public inputs are [0]: an explicit zero column
+        dev_pi = ctx.alloc(n)
+        dev_pi.upload(host_pi)
+        same = lambda a, b: bool((np.asarray(a[0]) == np.asarray(b[0])).all() and int(a[1]) == int(b[1]))   # noqa: E731
+        for with_pi in (True, False):
+            ref = ctx.prove_native(sid, chain.circuit, chain.wire_evals, dev_pi if with_pi else None, chain.cosets)
+            got = ctx.prove_native_host(sid, chain.circuit, host_w, host_pi if with_pi else None, chain.cosets)
+            for key in ("commit", "t_commit", "witness"):
+                assert all(same(a, b) for a, b in zip(got[key], ref[key])), (key, with_pi)
+            assert same(got["z_commit"], ref["z_commit"])
+            assert all((a == b).all() for a, b in zip(got["evals"], ref["evals"]))
+            assert all((got["challenges"][k] == ref["challenges"][k]).all() for k in ("beta", "gamma", "alpha", "zeta"))
+            assert not got["evals"][5].any()
+        import ctypes as C
+
+        w = (C.POINTER(C.c_uint64) * 3)()          # three null columns
+        from typlonk_amd.capi import Proof
+
+        ks = ((C.c_uint64 * 4) * 3)()
+        rc = ctx.lib.typlonk_prove_host(ctx.h, sid, chain.circuit, w, None, C.byref(ks), C.byref(Proof()))
+        assert rc == ERR_INVALID_ARG
+        dev_pi.free()
+    finally:
+        chain.free()
+        ctx.srs_free(sid)
+
+
 @pytest.mark.parametrize("pipe", ["0", "1"])
 def test_round3_queueing_switch_does_not_change_a_bit(built, monkeypatch, pipe):
     """TYPLONK_PROVER_PIPE: round 3's nine commitments behind one fence (round 5, the default) or queued as rounds 1-4

@@ -24,7 +24,7 @@ SYMBOLS = [
     "typlonk_msm_g1_dev", "typlonk_msm_g1_devptr", "typlonk_msm_g1_batch_devptr", "typlonk_ntt_fr", "typlonk_ntt_fr_dev",
     "typlonk_ntt_fr_devptr", "typlonk_ntt_fr_batch_devptr", "typlonk_quotient_dev", "typlonk_grand_product_dev", "typlonk_open_dev", "typlonk_lincomb_dev", "typlonk_prover_round1", "typlonk_prover_round2",
     "typlonk_prover_round3", "typlonk_prover_round3_evals", "typlonk_prover_round4_batched", "typlonk_prover_free",
-    "typlonk_prove", "typlonk_transcript_challenges", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
+    "typlonk_prove", "typlonk_prove_host", "typlonk_transcript_challenges", "typlonk_circuit_load", "typlonk_circuit_free", "typlonk_buf_alloc", "typlonk_buf_free", "typlonk_buf_upload",
     "typlonk_buf_download", "typlonk_buf_zero", "typlonk_buf_len", "typlonk_buf_devptr",
     "typlonk_g1_sum_host", "typlonk_set_profiling", "typlonk_profile_get", "typlonk_msm_plan", "typlonk_selftest_fq_inv",
     "typlonk_version",
@@ -141,6 +141,8 @@ def load_library() -> C.CDLL:
     lib.typlonk_prover_round3_evals.argtypes = [vp, u64p, u64p, C.POINTER(ProofEvals)]
     lib.typlonk_prover_round4_batched.argtypes = [vp, u64p, C.POINTER(ProofBatched)]
     lib.typlonk_prove.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp), vp, C.POINTER((C.c_uint64 * 4) * 3), C.POINTER(Proof)]
+    if hasattr(lib, "typlonk_prove_host") or not os.environ.get("TYPLONK_LIB_PATH"):   # (as typlonk_ntt_fr_batch_devptr above)
+        lib.typlonk_prove_host.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(u64p), u64p, C.POINTER((C.c_uint64 * 4) * 3), C.POINTER(Proof)]
     lib.typlonk_transcript_challenges.argtypes = [u64p, u8p, C.c_size_t, C.c_size_t, u64p]
     lib.typlonk_prover_free.argtypes = [vp]
     lib.typlonk_prover_free.restype = None
@@ -574,6 +576,27 @@ class Context:
         pr = Proof()
         self._chk(self.lib.typlonk_prove(self.h, sid, circuit, w, pi_evals.handle if pi_evals is not None else None,
                                          C.byref(ks), C.byref(pr)))
+        t = pr.tail
+        return {
+            "commit": [(np.array(pr.commit_xy[i], dtype=np.uint64), int(pr.commit_inf[i])) for i in range(3)],
+            "z_commit": (np.array(pr.z_xy, dtype=np.uint64), int(pr.z_inf)),
+            "t_commit": [(np.array(t.t_xy[i], dtype=np.uint64), int(t.t_inf[i])) for i in range(3)],
+            "witness": [(np.array(t.w_xy[i], dtype=np.uint64), int(t.w_inf[i])) for i in range(6)],
+            "evals": [np.array(t.evals[i], dtype=np.uint64) for i in range(6)],
+            "challenges": {k: np.array(getattr(pr, k), dtype=np.uint64) for k in ("beta", "gamma", "alpha", "zeta")},
+        }
+
+    def prove_native_host(self, sid: int, circuit: int, wire_evals_host, pi_evals_host, cosets):
+        """typlonk_prove_host: the columns are (n, 4) u64 arrays in host memory; uploaded column by column beside round 1"""
+        cols = [np.ascontiguousarray(_as_u64(w, 4)) for w in wire_evals_host]
+        w = (C.POINTER(C.c_uint64) * 3)(*[_u64p(c) for c in cols])
+        pi = np.ascontiguousarray(_as_u64(pi_evals_host, 4)) if pi_evals_host is not None else None
+        ks = ((C.c_uint64 * 4) * 3)()
+        for i in range(3):
+            for j, limb in enumerate(np.asarray(cosets[i], dtype=np.uint64).reshape(4)):
+                ks[i][j] = int(limb)
+        pr = Proof()
+        self._chk(self.lib.typlonk_prove_host(self.h, sid, circuit, w, _u64p(pi) if pi is not None else None, C.byref(ks), C.byref(pr)))
         t = pr.tail
         return {
             "commit": [(np.array(pr.commit_xy[i], dtype=np.uint64), int(pr.commit_inf[i])) for i in range(3)],

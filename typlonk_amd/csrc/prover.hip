@@ -398,10 +398,40 @@ int prover_open(typlonk_prover* p, const Fr* poly, uint64_t m, const Fr& z, Fr* 
 }
 }  // namespace
 
+namespace {
+// One column of round 1's input: n evaluations on the device (a typlonk_buf) or still on the HOST (typlonk_prove_host: the
+// reference's prove() holds its padded, blinded columns as Vec<Fr>, plonk/src/proof.rs:43-49).
+struct ColumnSrc {
+    const Fr* dev = nullptr;
+    const uint64_t* host = nullptr;
+    bool present() const { return dev || host; }
+};
+int prover_round1_impl(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const ColumnSrc (&wires)[3], const ColumnSrc& pi,
+                       typlonk_prover** out, uint64_t commit_xy[3][12], uint8_t commit_inf[3]);
+}  // namespace
+
 int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
                           const typlonk_buf* pi_evals, typlonk_prover** out, uint64_t commit_xy[3][12],
                           uint8_t commit_inf[3]) {
     if (!ctx || !wire_evals || !out || !commit_xy || !commit_inf) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    auto ci = ctx->circuits.find(circuit_id);
+    if (ci == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
+    const uint64_t n = 1ull << ci->second.log_n;
+    ColumnSrc w[3], pi;
+    for (int i = 0; i < 3; ++i) {
+        if (!wire_evals[i] || wire_evals[i]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "wire column shorter than n");
+        w[i].dev = wire_evals[i]->d;
+    }
+    if (pi_evals) {
+        if (pi_evals->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "public-input column shorter than n");
+        pi.dev = pi_evals->d;
+    }
+    return prover_round1_impl(ctx, srs_id, circuit_id, w, pi, out, commit_xy, commit_inf);
+}
+
+namespace {
+int prover_round1_impl(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const ColumnSrc (&wires)[3], const ColumnSrc& pi_src,
+                       typlonk_prover** out, uint64_t commit_xy[3][12], uint8_t commit_inf[3]) {
     HIPCHK(hipSetDevice(ctx->device));
     auto ci = ctx->circuits.find(circuit_id);
     if (ci == ctx->circuits.end()) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
@@ -411,9 +441,6 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     int rc = msm_validate(ctx, srs_id, n, &srs);  // every committed polynomial has <= n coefficients
     if (rc) return rc;
     if (n > (1u << 22)) return fail(ctx, TYPLONK_ERR_LENGTH, "prover supports up to 2^22 rows");
-    for (int i = 0; i < 3; ++i)
-        if (!wire_evals[i] || wire_evals[i]->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "wire column shorter than n");
-    if (pi_evals && pi_evals->n < n) return fail(ctx, TYPLONK_ERR_RANGE, "public-input column shorter than n");
     if (ctx->prover_busy) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "a proof is already in flight on this context");
     rc = ensure(ctx, ctx->prover_mem, (uint64_t)19 * n * sizeof(Fr));  // 3+3+1+1+4+6+1 vectors, kept across proofs
     if (rc) return rc;
@@ -443,17 +470,25 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
         const hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(Fr), hipMemcpyDeviceToDevice, s);
         return e == hipSuccess ? TYPLONK_OK : fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(e));
     };
+    // a column into its place on the device: device -> device, or host -> device on the context's stream -- issued column by
+    // column, each right before that column's transform and commitment are queued, so column i + 1 crosses PCIe while column i
+    // is being transformed, sorted and accumulated
+    auto fetch = [&](Fr* dst, const ColumnSrc& c) -> int {
+        if (c.dev) return d2d(dst, c.dev);
+        const hipError_t e = hipMemcpyAsync(dst, c.host, n * sizeof(Fr), hipMemcpyHostToDevice, s);
+        return e == hipSuccess ? TYPLONK_OK : fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(e));
+    };
     MsmQueue q(ctx, srs, /*first_lane=*/1);
-    p->has_pi = pi_evals != nullptr;  // NULL: public inputs [0] -> the zero polynomial
+    p->has_pi = pi_src.present();  // absent: public inputs [0] -> the zero polynomial
     if (ctx->prover_ntt_batch == 1 || ctx->prover_ntt_batch == 2) {
         // mode 1: the three interpolations (and the public-input column's, proof.rs:105-106) as ONE batched transform
         // (ntt_run_batch), then the three commitments; mode 2: the first column alone -- its commitment starts at once --
         // and the others as one batch beside it.  Either way the coset extensions of the group are one batch.
         for (int i = 0; i < 3 && !rc; ++i) {
-            if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
-            rc = d2d(p->co[i], wire_evals[i]->d);
+            if ((rc = fetch(p->ev[i], wires[i]))) break;
+            rc = d2d(p->co[i], p->ev[i]);
         }
-        if (!rc && p->has_pi) rc = d2d(p->pi, pi_evals->d);
+        if (!rc && p->has_pi) rc = fetch(p->pi, pi_src);
         Fr* grp[4] = {p->co[0], p->co[1], p->co[2], p->pi};
         const size_t cnt = p->has_pi ? 4 : 3;
         if (ctx->prover_ntt_batch == 2) {
@@ -469,13 +504,13 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
         if (!rc) rc = prover_extend_batch(p, slots, grp, cnt);
     } else {
         for (int i = 0; i < 3 && !rc; ++i) {
-            if ((rc = d2d(p->ev[i], wire_evals[i]->d))) break;
-            if ((rc = d2d(p->co[i], wire_evals[i]->d))) break;
+            if ((rc = fetch(p->ev[i], wires[i]))) break;
+            if ((rc = d2d(p->co[i], p->ev[i]))) break;
             if ((rc = ntt_run(ctx, p->co[i], log_n, 1, nullptr, false))) break;
             rc = q.submit(p->co[i], n, commit_xy[i], commit_inf + i);
         }
         if (!rc && p->has_pi) {
-            rc = d2d(p->pi, pi_evals->d);
+            rc = fetch(p->pi, pi_src);
             if (!rc) rc = ntt_run(ctx, p->pi, log_n, 1, nullptr, false);  // proof.rs:105-106
         }
         // the coset transforms of the quotient's per-proof inputs run beside the commitments (measured: -1 % per proof;
@@ -502,6 +537,7 @@ int typlonk_prover_round1(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id
     *out = p;
     return TYPLONK_OK;
 }
+}  // namespace
 
 int typlonk_prover_round2(typlonk_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t cosets[3][4],
                           uint64_t z_xy[12], uint8_t* z_inf) {
@@ -785,16 +821,48 @@ int typlonk_transcript_challenges(const uint64_t* xy, const uint8_t* inf, size_t
     return TYPLONK_OK;
 }
 
+namespace {
+int prove_impl(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const* wire_bufs, const typlonk_buf* pi_buf,
+               const uint64_t* const* wire_host, const uint64_t* pi_host, const uint64_t cosets[3][4], typlonk_proof* out);
+}  // namespace
+
 int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const wire_evals[3],
                   const typlonk_buf* pi_evals, const uint64_t cosets[3][4], typlonk_proof* out) {
     if (!ctx || !wire_evals || !cosets || !out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    return prove_impl(ctx, srs_id, circuit_id, wire_evals, pi_evals, nullptr, nullptr, cosets, out);
+}
+
+int typlonk_prove_host(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const uint64_t* const wire_evals[3],
+                       const uint64_t* pi_evals, const uint64_t cosets[3][4], typlonk_proof* out) {
+    if (!ctx || !wire_evals || !cosets || !out) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < 3; ++i)
+        if (!wire_evals[i]) return fail(ctx, TYPLONK_ERR_INVALID_ARG, "null wire column");
+    return prove_impl(ctx, srs_id, circuit_id, nullptr, nullptr, wire_evals, pi_evals, cosets, out);
+}
+
+namespace {
+int prove_impl(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const typlonk_buf* const* wire_bufs, const typlonk_buf* pi_buf,
+               const uint64_t* const* wire_host, const uint64_t* pi_host, const uint64_t cosets[3][4], typlonk_proof* out) {
     typlonk_prover* p = nullptr;
     // An SRS shard on a context with a communicator: every round's partial commitments are folded over the ranks (one
     // all-gather per round), so all ranks hash the same points and end with the same proof.  A rank whose round fails
     // (an OOM, say) still joins that round's collective with flagged records, so its peers return TYPLONK_ERR_COMM
     // instead of waiting for ever (comm_fold).
     const bool folds = comm_folds(ctx, srs_id);
-    int rc = typlonk_prover_round1(ctx, srs_id, circuit_id, wire_evals, pi_evals, &p, out->commit_xy, out->commit_inf);
+    int rc;
+    if (wire_host) {   // the columns are on the host: each is uploaded right before its transform and commitment are queued
+        auto ci = ctx->circuits.find(circuit_id);
+        if (ci == ctx->circuits.end()) {
+            rc = fail(ctx, TYPLONK_ERR_INVALID_ARG, "unknown circuit id");
+        } else {
+            ColumnSrc w[3], pi;
+            for (int i = 0; i < 3; ++i) w[i].host = wire_host[i];
+            pi.host = pi_host;
+            rc = prover_round1_impl(ctx, srs_id, circuit_id, w, pi, &p, out->commit_xy, out->commit_inf);
+        }
+    } else {
+        rc = typlonk_prover_round1(ctx, srs_id, circuit_id, wire_bufs, pi_buf, &p, out->commit_xy, out->commit_inf);
+    }
     if (folds) rc = comm_fold(ctx, &out->commit_xy[0][0], out->commit_inf, 3, rc);
     if (rc) {
         if (p) typlonk_prover_free(p);
@@ -836,6 +904,7 @@ int typlonk_prove(typlonk_ctx* ctx, uint32_t srs_id, uint32_t circuit_id, const 
     typlonk_prover_free(p);
     return rc;
 }
+}  // namespace
 
 void typlonk_prover_free(typlonk_prover* p) {
     if (!p) return;
