@@ -534,29 +534,16 @@ class CompiledCircuit {
     // empty for the all-zero one (:52-53).  A witness that does not satisfy the circuit throws (the reference panics).
     Proof prove(const std::vector<Fr> (&advice)[3], const std::vector<Fr>& public_inputs = {}) const {
         typlonk_ctx* c = srs_.ctx().raw();
-        typlonk_buf* w[3] = {nullptr, nullptr, nullptr};
-        typlonk_buf* pi = nullptr;
         typlonk_proof raw;
-        int rc = TYPLONK_OK;
-        try {
-            for (int i = 0; i < 3; ++i) {
-                if (advice[i].size() != n_) throw std::runtime_error("witness column must hold n values");
-                w[i] = upload(advice[i]);
-            }
-            if (!public_inputs.empty()) {
-                if (public_inputs.size() != n_) throw std::runtime_error("public-input column must hold n values");
-                pi = upload(public_inputs);
-            }
-            uint64_t ks[3][4];
-            for (int i = 0; i < 3; ++i) std::memcpy(ks[i], cosets_[i].limbs(), 32);
-            const typlonk_buf* wc[3] = {w[0], w[1], w[2]};
-            rc = typlonk_prove(c, srs_.id(), circuit_, wc, pi, ks, &raw);
-        } catch (...) {
-            release(w, pi);
-            throw;
-        }
-        release(w, pi);
-        check(rc, c);
+        // the columns go over as they are, in host memory (typlonk_prove_host: each is uploaded right before its
+        // interpolation and commitment are queued, beside the previous column's kernels) -- as the Rust layer's Backend::prove
+        for (int i = 0; i < 3; ++i)
+            if (advice[i].size() != n_) throw std::runtime_error("witness column must hold n values");
+        if (!public_inputs.empty() && public_inputs.size() != n_) throw std::runtime_error("public-input column must hold n values");
+        uint64_t ks[3][4];
+        for (int i = 0; i < 3; ++i) std::memcpy(ks[i], cosets_[i].limbs(), 32);
+        const uint64_t* wc[3] = {advice[0][0].limbs(), advice[1][0].limbs(), advice[2][0].limbs()};
+        check(typlonk_prove_host(c, srs_.id(), circuit_, wc, public_inputs.empty() ? nullptr : public_inputs[0].limbs(), ks, &raw), c);
         Proof p;
         auto pt = [](const uint64_t xy[12], uint8_t inf) {
             kzg::G1Point g;
@@ -664,11 +651,6 @@ class CompiledCircuit {
             check(rc, c);
         }
         return b;
-    }
-    void release(typlonk_buf* (&w)[3], typlonk_buf* pi) const {
-        for (typlonk_buf* b : w)
-            if (b) typlonk_buf_free(srs_.ctx().raw(), b);
-        if (pi) typlonk_buf_free(srs_.ctx().raw(), pi);
     }
     const kzg::Srs& srs_;
     uint32_t log_n_;
