@@ -50,3 +50,6 @@ find $O -name "*counter_collection.csv" -size +2M -delete
 python3 bench.py --log-n 22 --cpu-sample 8192 --steps 10 --warmup 3 > $O/bench_2_22.json 2> $O/bench_2_22.err
 python3 tools/srs_setup_bench.py > $O/srs_setup.jsonl 2>/dev/null
 ls -la $O | head -50; tail -c 1500 $O/bench_full.json; cat $O/shard_latency.jsonl; tail -25 $O/prove_timeline.txt; cat $O/prove_rounds.txt | tail -3; cat $O/prove_rounds_2_22.txt; cat $O/msm_2_20_timeline.txt; cat $O/pmc_sq_ntt_batched.json
+# the host-memory seams (the reference's commit() and prove() as a host caller sees them)
+python3 tools/msm_host_path.py 2>/dev/null | grep HOSTPATH > $O/host_scalar_path.txt
+python3 tools/prove_host_path.py 2>/dev/null | grep PROVEHOST > $O/prove_host_path.txt
