@@ -345,7 +345,11 @@ int typlonk_g1_fold_records_host(const uint64_t* records, size_t world, size_t c
 /* ---- measurement -------------------------------------------------------------------------------
  * With profiling on, every kernel stage of the next MSM / NTT call is bracketed by HIP events on
  * the context's stream.  typlonk_profile_get returns up to `cap` (name, milliseconds) pairs of the
- * last call and the number of stages it had. */
+ * last call and the number of stages it had.
+ *   on = 0  off
+ *   on = 1  every stage (sort, accumulate, reduce, NTT passes ...): ~0.1 ms of event traffic per MSM, and NTT calls wait
+ *           for their result
+ *   on = 2  the dominant kernel only (the bucket accumulation launches, "msm_accum"): what a timed loop can afford */
 int typlonk_set_profiling(typlonk_ctx* ctx, int on);
 int typlonk_profile_get(typlonk_ctx* ctx, const char** names, float* ms, int cap);
 /* Pippenger shape chosen for an m-term MSM: window bits c, number of windows, and the number of

@@ -644,7 +644,8 @@ class Context:
         return DeviceBuffer(self, n)
 
     # ---- measurement ----------------------------------------------------------------------
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """False / 0 off, True / 1 every stage, 2 the bucket-accumulation launches only (cheap enough for a timed loop)"""
         self._chk(self.lib.typlonk_set_profiling(self.h, int(on)))
 
     def profile(self) -> list[tuple[str, float]]:

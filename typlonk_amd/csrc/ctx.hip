@@ -217,6 +217,7 @@ void* typlonk_buf_devptr(const typlonk_buf* buf) { return buf ? (void*)buf->d : 
 int typlonk_set_profiling(typlonk_ctx* ctx, int on) {
     if (!ctx) return TYPLONK_ERR_INVALID_ARG;
     ctx->profiling = on != 0;
+    ctx->prof_light = on == 2;
     return TYPLONK_OK;
 }
 

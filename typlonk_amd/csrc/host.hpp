@@ -199,6 +199,7 @@ struct typlonk_ctx {
                                    // faster (ntt_run_batch), 2 = for every 2^20 transform outside a prover round
     // profiling
     bool profiling = false;
+    bool prof_light = false;       // typlonk_set_profiling(ctx, 2): only the bucket-accumulation launches are bracketed
     std::vector<tyh::ProfStage> prof;
     std::vector<hipEvent_t> event_pool;  // timing events of finished stages, reused by the next call
     std::vector<std::pair<const char*, float>> prof_result;
@@ -262,7 +263,8 @@ struct StageTimer {
     hipEvent_t a = nullptr, b = nullptr;
     const char* name;
     hipStream_t st;
-    StageTimer(typlonk_ctx* c, const char* n, hipStream_t s = nullptr) : ctx(c), on(c->profiling), name(n), st(s ? s : c->stream) {
+    StageTimer(typlonk_ctx* c, const char* n, hipStream_t s = nullptr)
+        : ctx(c), on(c->profiling && (!c->prof_light || strcmp(n, "msm_accum") == 0)), name(n), st(s ? s : c->stream) {
         if (on) {
             a = take();
             b = take();

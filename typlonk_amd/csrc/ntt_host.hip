@@ -468,7 +468,7 @@ int ntt_run_batch(typlonk_ctx* ctx, Fr* const* d_data, size_t count, uint32_t lo
         rows *= M;
         row_len /= M;
     }
-    if (sync || ctx->profiling) HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (sync || (ctx->profiling && !ctx->prof_light)) HIPCHK(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     return TYPLONK_OK;
 }
