@@ -189,18 +189,20 @@ __global__ __launch_bounds__(RC2_THREADS) void msm_rc2_planes_kernel(const uint3
     }
     __syncthreads();
     if (wave != 0) return;
+    // the wavefronts' sums, each on a lane PAIR (lanes 2w, 2w + 1), so that the steps across them are four-lane steps too
     v = G1Xyzz::inf();
-    if (threadIdx.x < nwaves) {
+    if (threadIdx.x < 2 * nwaves) {
+        const uint32_t w = threadIdx.x >> 1;
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
-            v.x.v[i] = xch[threadIdx.x][i];
-            v.y.v[i] = xch[threadIdx.x][13 + i];
-            v.zz.v[i] = xch[threadIdx.x][26 + i];
-            v.zzz.v[i] = xch[threadIdx.x][39 + i];
+            v.x.v[i] = xch[w][i];
+            v.y.v[i] = xch[w][13 + i];
+            v.zz.v[i] = xch[w][26 + i];
+            v.zzz.v[i] = xch[w][39 + i];
         }
     }
 #pragma unroll 1
-    for (int mask = 1; mask < (int)nwaves; mask <<= 1) v = butterfly_add(v, mask);
+    for (int mask = 2; mask < (int)(2 * nwaves); mask <<= 1) v = butterfly_add4(v, mask);
     if (threadIdx.x == 0) st_xyzz(out, blockIdx.x, v);
 }
 
