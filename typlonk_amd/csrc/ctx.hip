@@ -96,7 +96,8 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         ctx->msm_rc2_force = (strcmp(e, "rc2") == 0);
     }
     if (const char* e = getenv("TYPLONK_MSM_SCATTER")) ctx->msm_scatter_staged = strcmp(e, "direct") != 0;
-    if (const char* e = getenv("TYPLONK_MSM_L1_THREADS")) ctx->msm_l1_threads = atoi(e) == 256 ? 256 : 512;
+    if (const char* e = getenv("TYPLONK_MSM_L1_THREADS")) ctx->msm_l1_threads = atoi(e) == 256 ? 256 : (atoi(e) == 512 ? 512 : 0);
+    if (const char* e = getenv("TYPLONK_MSM_SORT_PRIO")) ctx->msm_sort_prio = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_MSM_CHAIN")) ctx->msm_chain = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("TYPLONK_MSM_LANES")) {
         const int l = atoi(e);

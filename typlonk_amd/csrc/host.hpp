@@ -123,7 +123,8 @@ struct typlonk_buf {
 //   TYPLONK_MSM_CHUNKS    chunks of a stand-alone MSM (0 = by length)
 //   TYPLONK_MSM_LANES     lanes per bucket of the accumulation (1, 2, 4, 8, 16; 0 = by bucket load)
 //   TYPLONK_MSM_SCATTER   staged | direct: level 1 of the bucket sort stages its runs in the LDS / writes entry by entry
-//   TYPLONK_MSM_L1_THREADS 256 | 512: workgroup size of the sort's level-1 passes
+//   TYPLONK_MSM_L1_THREADS 256 | 512: workgroup size of the sort's level-1 passes (default: by whether the sort runs beside an accumulation)
+//   TYPLONK_MSM_SORT_PRIO 0 | 1: raised wavefront priority + 256-thread level 1 for the sorts of a stand-alone MSM's overlapped chunks
 //   TYPLONK_MSM_REDUCE    rc2 | rc4: force the two- / four-launch row/column bucket reduction
 //   TYPLONK_NTT_FR30      0 | 1 | 2: the 9 x 30-bit butterflies never / where they measure faster / always
 //   TYPLONK_NTT_BIG       0 | 1 | 2: the two-pass 2^20 plan (4096-element tiles) never / where it measures faster / always
@@ -178,9 +179,11 @@ struct typlonk_ctx {
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_scatter_staged = true;  // TYPLONK_MSM_SCATTER=direct: level 1 of the bucket sort writes every entry straight to global
                                    // memory (the rounds 1-5 form, the A/B reference) instead of staging runs in the LDS
-    int msm_l1_threads = 512;      // TYPLONK_MSM_L1_THREADS = 256 | 512: threads per workgroup of the sort's level-1 passes (staged form);
-                                   // 512 (two wavefronts per SIMD): histogram 18.5 -> 14.3 us, scatter 49.3 -> 32.6 us per 2^19 terms,
-                                   // nine-MSM batch 2.494 -> 2.477 ms per MSM (profiles/r06_ab_sort.txt)
+    int msm_l1_threads = 0;        // TYPLONK_MSM_L1_THREADS = 256 | 512: threads per workgroup of the sort's level-1 passes (staged form);
+                                   // 0 = 512 for a sort that has the chip to itself (histogram 18.5 -> 14 us, scatter 49 -> 32 us per
+                                   // 2^19 terms), 256 for an overlapped chunk's (msm_enqueue)
+    bool msm_sort_prio = true;     // TYPLONK_MSM_SORT_PRIO=0: the overlapped chunks' sorts get neither the raised wavefront priority
+                                   // nor the 256-thread shape (the A/B reference)
     bool msm_rc4 = false;          // always the four-launch row/column reduction
     bool msm_rc2_force = false;    // the two-launch form for every bucket-set size
     // NTT

@@ -90,13 +90,14 @@ void launch_scan(const uint32_t* counts, uint64_t n, uint32_t* block_sums, uint3
                  hipStream_t s);
 uint32_t msm_segsort_blocks(uint64_t m);  // workgroups of the level-1 passes for an m-term MSM
 uint32_t msm_sched_words();               // words of the bucket-schedule counters (hist514 of the calls below)
-// the whole segmented bucket sort of one chunk, bucket schedule (order[]) included; blk_cnt: nseg * nblk words (the staged
+// the whole segmented bucket sort of one chunk, bucket schedule (order[]) included; beside_accum: the sort runs beside an
+// accumulation (raised wavefront priority); blk_cnt: nseg * nblk words (the staged
 // level-1 scatter's per-workgroup count rows; NULL = direct scatter), seg_start: 2 * nseg words
 void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, uint32_t top_v, uint32_t hb,
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries, uint32_t* counts,
                         uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks,
-                        uint32_t* order, bool centred, int staged_mode, uint32_t l1_threads, hipStream_t s);
+                        uint32_t* order, bool centred, int staged_mode, uint32_t l1_threads, bool beside_accum, hipStream_t s);
 // windows of the signed c-bit digit decomposition.  Scalars are canonical (< r < 2^255): the top window holds
 // t = bits - c (W0 - 1) bits, W0 = ceil(bits / c), and a digit <= 2^t cannot exceed 2^(c-1) (no carry out of it) unless
 // t = c.  Centred scalars (|k| <= (r - 1)/2 < 2^254) have one bit less: c = 17 -> 15 windows instead of 16.

@@ -196,12 +196,21 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
             if ((rc = ensure(ctx, sb.seg_start, seg.nseg * 8))) return rc;
             if ((rc = ensure(ctx, sb.blocksums, (size_t)((seg.nmat + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + scan_blocks + seg.nseg) * 4))) return rc;
             blocksums = (uint32_t*)sb.blocksums.p;
+            // The sort of an OVERLAPPED chunk (side stream, beside the previous chunk's accumulation) takes 256-thread level-1
+            // workgroups -- one 70-register wavefront per SIMD fits next to two 200-register accumulation wavefronts; two
+            // do not, and the kernel then waits for the accumulation to drain -- and a raised wavefront priority: its five
+            // kernels finish in 0.14 ms instead of trailing the whole accumulation (0.95 ms), and the next accumulation
+            // starts 6 us after the previous one instead of 56 (profiles/r06_ab_sort_prio.txt).  The exposed first sort has
+            // the chip to itself and takes 512.  NOT for the queued MSMs of a batch: there it is neutral to slightly
+            // negative (the sorts steal from another MSM's accumulation what they gain).  TYPLONK_MSM_L1_THREADS forces one.
+            const bool beside = ctx->msm_sort_prio && ss != s;
+            const uint32_t l1 = ctx->msm_l1_threads ? (uint32_t)ctx->msm_l1_threads : (beside ? 256u : 512u);
             StageTimer st(ctx, ss == s ? "msm_sort" : "msm_sort_overlapped", ss);
             launch_msm_segsort(sc, (uint64_t)mk, c, W, digit_v, (uint32_t)seg.hb, seg.ibits, tables ? (uint32_t)srs.len : 0u,
                                tables ? nsets : 0u, (uint32_t*)sb.blk_hist.p, (uint32_t*)sb.blk_base.p, blocksums,
                                (uint32_t*)sb.blk_cnt.p, (uint32_t*)sb.seg_start.p, keys, counts, offsets, sorted, cap,
                                (uint32_t*)sb.ohist.p, (uint32_t*)sb.heavy.p, (uint32_t*)sb.tasks.p, (uint32_t*)sb.order.p,
-                               centred, ctx->msm_scatter_staged ? 1 : 0, (uint32_t)ctx->msm_l1_threads, ss);
+                               centred, ctx->msm_scatter_staged ? 1 : 0, l1, beside, ss);
         } else {
             {
                 StageTimer st(ctx, "msm_digits", ss);

@@ -190,7 +190,14 @@ struct MsmShape {
     // centred scalars: k > (r - 1)/2 is replaced by r - k with every digit's sign flipped, so |k| < 2^254 and
     // c = 17 needs 15 windows instead of 16, c = 15 17 instead of 18 (launch.hpp, msm_windows)
     uint32_t centred;
+    // > 0: the kernels of this sort raise their wavefronts' issue priority (s_setprio).  Set for a sort that runs BESIDE an
+    // accumulation (an overlapped chunk, a queued MSM): its few, short wavefronts then get the issue slots they ask for
+    // instead of the ones two accumulation wavefronts per SIMD leave over.
+    uint32_t prio;
 };
+__device__ __forceinline__ void msm_sort_prio(const MsmShape& sh) {
+    if (sh.prio) __builtin_amdgcn_s_setprio(2);
+}
 
 // Column of workgroup `blk` in the workgroup x segment matrix = its place inside every segment's output range.
 // Workgroups are dealt to the eight XCDs round-robin (blk mod 8), each XCD with its own L2: with the columns ordered by
@@ -323,6 +330,7 @@ template <uint32_t C>
 __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, uint64_t m, MsmShape sh,
                                                             uint32_t* blk_hist, uint32_t* blk_cnt) {
     extern __shared__ uint32_t seg_h[];
+    msm_sort_prio(sh);
     const uint32_t nt = blockDim.x;
     for (uint32_t s = threadIdx.x; s < sh.nseg; s += nt) seg_h[s] = 0;
     __syncthreads();
@@ -348,9 +356,10 @@ __global__ __launch_bounds__(1024) void msm_seg_hist_kernel(const Fr* scalars, u
 // redoes in LDS (msm_seg_starts).  Workgroup 0 also clears the bucket-schedule counters (`zero`).
 __global__ __launch_bounds__(256) void msm_seg_prefix_kernel(const uint32_t* __restrict__ blk_hist, uint32_t nblk,
                                                              uint32_t* blk_base, uint32_t* seg_tot, uint32_t* zero,
-                                                             uint32_t nzero) {
+                                                             uint32_t nzero, uint32_t prio) {
     __shared__ uint32_t buf[256];
     __shared__ uint32_t running;
+    if (prio) __builtin_amdgcn_s_setprio(2);
     {   // every workgroup clears its slice
         const uint32_t per = (nzero + gridDim.x - 1) / gridDim.x;
         for (uint32_t i = blockIdx.x * per + threadIdx.x; i < min((blockIdx.x + 1) * per, nzero); i += 256) zero[i] = 0;
@@ -484,6 +493,7 @@ __global__ __launch_bounds__(512) void msm_seg_scatter_staged_kernel(const Fr* s
                                                                      const uint32_t* __restrict__ blk_cnt, uint32_t* seg_start,
                                                                      uint32_t* entries) {
     extern __shared__ uint32_t seg_sm[];
+    msm_sort_prio(sh);
     uint32_t* rank = seg_sm;
     uint32_t* loc = seg_sm + sh.nseg;
     uint32_t* gst = seg_sm + 2 * sh.nseg;
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(1024) void msm_seg_count_kernel(const uint32_t* __r
                                                              uint32_t* tasks) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
+    msm_sort_prio(sh);
     const uint32_t s = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
     uint32_t start, end;
     if (seg_tot) {  // the fused row-prefix form: the level-1 scatter has published every segment's range
@@ -662,6 +673,7 @@ __global__ __launch_bounds__(1024) void msm_seg_place_kernel(const uint32_t* __r
     // The segment's slice of `sorted` is contiguous (~3300 entries), so it is assembled here and copied out in whole lines.
     // A longer segment (adversarial scalars) writes directly.
     __shared__ uint32_t seg_out[MSM_PLACE_STAGE];
+    msm_sort_prio(sh);
     const uint32_t s = blockIdx.x, nt = blockDim.x, tid = threadIdx.x;
     const uint32_t start = seg_start[2 * s], end = seg_start[2 * s + 1];
     const uint32_t nlow = 1u << sh.lb;
@@ -863,7 +875,7 @@ static void launch_msm_segsort_c(const Fr* scalars, uint64_t m, const MsmShape& 
                        blk_hist, staged ? blk_cnt : (uint32_t*)nullptr);
     if (fused)
         hipLaunchKernelGGL(msm_seg_prefix_kernel, dim3(sh.nseg), dim3(256), 0, s, blk_hist, sh.nblk, blk_base, seg_tot, hist514,
-                           MSM_SCHED_WORDS);
+                           MSM_SCHED_WORDS, sh.prio);
     else
         launch_exclusive_scan(blk_hist, nmat, scan_scratch, blk_base, blk_hist /* second copy unused */, hist514, MSM_SCHED_WORDS, s);
     if (staged)
@@ -887,9 +899,10 @@ void launch_msm_segsort(const Fr* scalars, uint64_t m, uint32_t c, uint32_t W, u
                         uint32_t ibits, uint32_t tlen, uint32_t nsets, uint32_t* blk_hist, uint32_t* blk_base,
                         uint32_t* scan_scratch, uint32_t* blk_cnt, uint32_t* seg_start, uint32_t* entries, uint32_t* counts,
                         uint32_t* offsets, uint32_t* sorted, uint32_t cap, uint32_t* hist514, uint32_t* heavy, uint32_t* tasks,
-                        uint32_t* order, bool centred, int staged_mode, uint32_t l1_threads, hipStream_t s) {
+                        uint32_t* order, bool centred, int staged_mode, uint32_t l1_threads, bool beside_accum, hipStream_t s) {
     MsmShape sh;
     sh.centred = centred ? 1u : 0u;
+    sh.prio = beside_accum ? 1u : 0u;
     sh.c = c;
     sh.W = W;
     sh.top_v = top_v;
