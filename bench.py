@@ -337,6 +337,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warm-seconds", type=float, default=1.0,
+                    help="untimed steps after the --warmup steps until this much wall time has passed (clock ramp of a fresh box); 0 = none")
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16,
                     help="terms of the workload timed on the reference-faithful CPU MSM (2^16 ~ 16 s on one host core)")
@@ -471,6 +473,25 @@ def run(args, rank, world, backend, dev_index, device, result, state) -> None:
 
     for _ in range(args.warmup):
         step()
+    # ... and, on top of the W warm-up steps, untimed steps until the device has been busy for --warm-seconds: a fresh box
+    # (the first program after the lease) runs the first ~0.5 s of kernels at a lower clock -- the same MSM reads 2.51 ms
+    # as the first thing on a box and 2.40 ms after other work (profiles/r06_bench_full.json vs r06_bench_final_tree.json)
+    # (a COUNT, the same on every rank -- the steps of a sharded run contain collectives: rank 0's estimate is broadcast)
+    warm_extra = 0
+    if args.warm_seconds > 0:
+        torch.cuda.synchronize()
+        t_e = time.perf_counter()
+        for _ in range(3):                     # (three steps to price one, after the allocations of the first warm-up steps)
+            step()
+        est = max((time.perf_counter() - t_e) / 3, 1e-4)
+        warm_extra = min(2000, int(args.warm_seconds / est))
+    if world > 1:
+        t = torch.tensor([warm_extra], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        dist.broadcast(t, src=0)
+        warm_extra = int(t.item())
+    for _ in range(warm_extra):
+        step()
+    result["warm_extra_steps"] = warm_extra
     stage_ms, accum_launches = {}, 0
     sync_all()
     t0 = time.perf_counter()
