@@ -16,8 +16,22 @@ SEED = int(os.environ.get("FUZZ_SEED", "20261002"))
 MAX_LOG = int(os.environ.get("FUZZ_MAX_LOG", "17"))
 rng = np.random.default_rng(SEED)
 dev = torch.device("cuda", 0)
-ctx = typlonk_amd.Context(0)
 R = O.R
+SORT_FORMS = [{}, {}, {"TYPLONK_MSM_SCATTER": "direct"}, {"TYPLONK_MSM_L1_THREADS": "256"}, {"TYPLONK_MSM_L1_THREADS": "512"},
+              {"TYPLONK_MSM_SORT_PRIO": "0"}, {"TYPLONK_NTT_BIG": "1"}, {"TYPLONK_NTT_BIG": "2"}]
+SORT_KEYS = sorted({k for f in SORT_FORMS for k in f})
+
+
+def new_context():
+    """a context under one of the forms the library offers for the bucket sort / the 2^20 NTT plan (read at creation)"""
+    form = SORT_FORMS[int(rng.integers(0, len(SORT_FORMS)))]
+    for k in SORT_KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(form)
+    return typlonk_amd.Context(0), form
+
+
+ctx, form = new_context()
 
 
 def mont(v):
@@ -75,9 +89,15 @@ def same(a, b):
     return a[1] == b[1] and (a[1] == 1 or (np.asarray(a[0]) == np.asarray(b[0])).all())
 
 
-stats = {"msm": 0, "batch": 0, "shard": 0, "ntt": 0, "fail": 0}
+stats = {"msm": 0, "batch": 0, "shard": 0, "ntt": 0, "ntt_batch": 0, "contexts": 1, "fail": 0}
 t_end = time.time() + SECONDS
+rounds = 0
 while time.time() < t_end:
+    rounds += 1
+    if rounds % 8 == 0:
+        ctx.close()
+        ctx, form = new_context()
+        stats["contexts"] += 1
     # ---- one SRS, several MSMs over it
     L = int(rng.integers(1, 1 << int(rng.integers(1, MAX_LOG + 1)))) + 1
     secret = mont(int(rng.integers(2, 1 << 62)))
@@ -98,7 +118,7 @@ while time.time() < t_end:
         stats["msm"] += 1
         if not same(got, want):
             stats["fail"] += 1
-            print(f"FAIL msm L={L} m={m} tables={tables} scalars={name} seed={SEED}", flush=True)
+            print(f"FAIL msm L={L} m={m} tables={tables} scalars={name} form={form} seed={SEED}", flush=True)
     # ---- a batch against single calls
     if L >= 8:
         k = int(rng.integers(1, 10))
@@ -109,7 +129,7 @@ while time.time() < t_end:
         stats["batch"] += 1
         if not all(same(a, b) for a, b in zip(singles, batch)):
             stats["fail"] += 1
-            print(f"FAIL batch L={L} k={k} ms={ms} tables={tables} seed={SEED}", flush=True)
+            print(f"FAIL batch L={L} k={k} ms={ms} tables={tables} form={form} seed={SEED}", flush=True)
     ctx.srs_free(sid)
     # ---- index shards of one SRS against the whole
     if L >= 16:
@@ -153,7 +173,22 @@ while time.time() < t_end:
         stats["ntt"] += 1
         if not (got == want).all():
             stats["fail"] += 1
-            print(f"FAIL ntt log_n={log_n} inverse={inverse} coset={coset is not None} seed={SEED}", flush=True)
+            print(f"FAIL ntt log_n={log_n} inverse={inverse} coset={coset is not None} form={form} seed={SEED}", flush=True)
+    # ---- a group of transforms in one call against single calls
+    log_n = int(rng.integers(1, MAX_LOG + 1))
+    k = int(rng.integers(1, 12))
+    inverse = bool(rng.integers(0, 2))
+    coset = mont(int(rng.integers(2, 1 << 62))) if rng.random() < 0.5 else None
+    vecs = [to_dev(scalars(1 << log_n)[1]) for _ in range(k)]
+    singles = [v.clone() for v in vecs]
+    for v in singles:
+        ctx.ntt_devptr(v.data_ptr(), log_n, inverse=inverse, coset=coset)
+    ctx.ntt_batch_devptr([v.data_ptr() for v in vecs], log_n, inverse=inverse, coset=coset)
+    torch.cuda.synchronize()
+    stats["ntt_batch"] += 1
+    if not all(torch.equal(a, b) for a, b in zip(vecs, singles)):
+        stats["fail"] += 1
+        print(f"FAIL ntt_batch log_n={log_n} k={k} inverse={inverse} coset={coset is not None} form={form} seed={SEED}", flush=True)
 ctx.close()
 print(f"fuzz seed {SEED}, {SECONDS:.0f} s: {stats}")
 sys.exit(1 if stats["fail"] else 0)

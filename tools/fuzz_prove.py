@@ -21,7 +21,7 @@ def limbs(v):
     return np.array(O.fr_to_mont_limbs(int(v) % O.R), dtype=np.uint64)
 
 
-stats, t_end = {"proofs": 0, "fail": 0, "by_log_n": {}}, time.time() + SECONDS
+stats, t_end = {"proofs": 0, "host_column_proofs": 0, "fail": 0, "by_log_n": {}}, time.time() + SECONDS
 while time.time() < t_end:
     log_n = int(rng.integers(3, MAX_LOG + 1))
     n = 1 << log_n
@@ -49,6 +49,18 @@ while time.time() < t_end:
         if not ok:
             stats["fail"] += 1
             print(f"FAIL prove log_n={log_n} tables={tables} seed={SEED}", flush=True)
+    # the native proof (transcript challenges) from device buffers against the one from host columns
+    dev_proof = ctx.prove_native(sid, chain.circuit, chain.wire_evals, chain.pi_evals, chain.cosets)
+    host_proof = ctx.prove_native_host(sid, chain.circuit, [b.download() for b in chain.wire_evals],
+                                       chain.pi_evals.download() if chain.pi_evals is not None else None, chain.cosets)
+    ok = all((np.asarray(a[0]) == np.asarray(b[0])).all() and int(a[1]) == int(b[1])
+             for k in ("commit", "t_commit", "witness") for a, b in zip(host_proof[k], dev_proof[k]))
+    ok = ok and (np.asarray(host_proof["z_commit"][0]) == np.asarray(dev_proof["z_commit"][0])).all()
+    ok = ok and all((np.asarray(g) == np.asarray(e)).all() for g, e in zip(host_proof["evals"], dev_proof["evals"]))
+    stats["host_column_proofs"] += 1
+    if not ok:
+        stats["fail"] += 1
+        print(f"FAIL prove_host log_n={log_n} tables={tables} seed={SEED}", flush=True)
     chain.free()
     ctx.srs_free(sid)
 ctx.close()
