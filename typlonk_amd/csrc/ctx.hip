@@ -105,6 +105,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     }
     if (const char* e = getenv("TYPLONK_MSM_INFLIGHT")) ctx->msm_inflight = atoi(e);
     if (const char* e = getenv("TYPLONK_MSM_CHUNKS")) ctx->msm_chunks = std::max(0, std::min(atoi(e), MSM_MAX_CHUNKS));
+    if (const char* e = getenv("TYPLONK_MSM_FIRST_PCT")) ctx->msm_first_pct = std::max(0, std::min(atoi(e), 99));
     if (const char* e = getenv("TYPLONK_PROVER_PIPE")) ctx->prover_pipe = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_PROVER_NTT_BATCH")) ctx->prover_ntt_batch = std::max(0, std::min(atoi(e), 3));
     if (const char* e = getenv("TYPLONK_NTT_FR30")) ctx->ntt_fr30 = std::max(0, std::min(atoi(e), 2));

@@ -176,6 +176,7 @@ struct typlonk_ctx {
                                    // runs beside it (typlonk_circuit_load, a caller's interpolate groups)
     bool prover_pipe = true;       // TYPLONK_PROVER_PIPE (A/B switch of the round-5 queueing fix, prover_round3_core)
     int msm_chunks = 0;            // chunks of a stand-alone MSM (0 = choose by length)
+    int msm_first_pct = 0;         // share of the terms in the first chunk, per cent (0 = equal chunks)
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)
     bool msm_scatter_staged = true;  // TYPLONK_MSM_SCATTER=direct: level 1 of the bucket sort writes every entry straight to global
                                    // memory (the rounds 1-5 form, the A/B reference) instead of staging runs in the LDS

@@ -124,7 +124,12 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         // commitment of a 2^22-row proof).
         nch = (uint32_t)std::min<size_t>((m + ((size_t)1 << 20) - 1) >> 20, MSM_MAX_CHUNKS);
     }
-    const size_t step = (m + nch - 1) / nch;
+    // chunk k = terms [cut(k), cut(k + 1)): equal shares, or -- stand-alone MSMs, TYPLONK_MSM_FIRST_PCT -- a first chunk of
+    // that share of the terms (its sort is the exposed one) and equal shares of the rest
+    const size_t first = (standalone && nch > 1 && ctx->msm_first_pct > 0 && ctx->msm_first_pct < 100)
+                             ? std::max<size_t>(4096, (m / 100 * (size_t)ctx->msm_first_pct) & ~(size_t)63) : 0;
+    const size_t step = first ? (m - first + nch - 2) / (nch - 1) : (m + nch - 1) / nch;
+    auto cut = [&](uint32_t k) { return k == 0 ? (size_t)0 : std::min(m, first ? first + (size_t)(k - 1) * step : (size_t)k * step); };
     hipStream_t s = ws.stream;
     int rc;
     const bool overlap = nch > 1 && standalone;   // chunk k + 1 sorted on the side stream while chunk k accumulates
@@ -144,9 +149,9 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
     uint32_t* buckets = (uint32_t*)ws.buckets.p;
 
     for (uint32_t k = 0; k < nch; ++k) {
-        const size_t off = (size_t)k * step;
+        const size_t off = cut(k);
         if (off >= m) break;
-        const size_t mk = std::min(step, m - off);
+        const size_t mk = cut(k + 1) - off;
         const Fr* sc = d_scalars + off;
         const uint32_t* pts = srs.d_points + off * PT_WORDS;  // chunk-local term index i -> base off + i (table t: + t*len)
         SortBufs& sb = ws.sb[k & 1];
