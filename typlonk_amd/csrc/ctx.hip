@@ -95,6 +95,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
         ctx->msm_rc4 = (strcmp(e, "rc4") == 0);
         ctx->msm_rc2_force = (strcmp(e, "rc2") == 0);
     }
+    if (const char* e = getenv("TYPLONK_MSM_RC2_LOGW")) ctx->msm_rc2_logw = std::max(8, std::min(atoi(e), 14));
     if (const char* e = getenv("TYPLONK_MSM_SCATTER")) ctx->msm_scatter_staged = strcmp(e, "direct") != 0;
     if (const char* e = getenv("TYPLONK_MSM_L1_THREADS")) ctx->msm_l1_threads = atoi(e) == 256 ? 256 : (atoi(e) == 512 ? 512 : 0);
     if (const char* e = getenv("TYPLONK_MSM_SORT_PRIO")) ctx->msm_sort_prio = atoi(e) != 0;

@@ -187,6 +187,7 @@ struct typlonk_ctx {
                                    // nor the 256-thread shape (the A/B reference)
     bool msm_rc4 = false;          // always the four-launch row/column reduction
     bool msm_rc2_force = false;    // the two-launch form for every bucket-set size
+    int msm_rc2_logw = 10;         // log2 wavefronts of the two-launch form's first launch (TYPLONK_MSM_RC2_LOGW)
     // NTT
     tyh::DevBuf ntt_scratch, ntt_io, quot_ext, quot_tab, ops_tmp, prover_mem;
     bool prover_busy = false;  // one proof in flight per context (the arena above is shared)

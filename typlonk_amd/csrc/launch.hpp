@@ -161,7 +161,7 @@ void launch_msm_rc_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* 
 // the same bit planes in two launches (msm_reduce.hip); needs cl, ch >= 6; prow, pcol: nsets << (c1 - 6) points each
 bool msm_rc2_ok(const RcShape& sh);
 void launch_msm_rc2_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* prow, uint32_t* pcol, uint32_t* out,
-                           hipStream_t s);
+                           uint32_t log_waves, hipStream_t s);
 void launch_msm_rc_combine(const uint32_t* planes, const RcShape& sh, uint32_t* set_sums, hipStream_t s);
 // comb: the fixed-base table of G (srs_comb_bytes() bytes, filled once by launch_srs_comb)
 // divsteps inversion against the Fermat ladder on threads * per_thread residues; out: {mismatches, max rounds, calls}

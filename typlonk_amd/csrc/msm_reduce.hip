@@ -209,10 +209,10 @@ __global__ __launch_bounds__(RC2_THREADS) void msm_rc2_planes_kernel(const uint3
 bool msm_rc2_ok(const RcShape& sh) { return sh.cl >= 6 && sh.ch >= 6; }
 // scratch: prow holds nsets << (c1 - 6 - sr) partials, pcol nsets << (c1 - 6 - sc); both <= nsets << (c1 - 6)
 void launch_msm_rc2_reduce(const uint32_t* buckets, const RcShape& sh, uint32_t* prow, uint32_t* pcol, uint32_t* out,
-                           hipStream_t s) {
+                           uint32_t log_waves, hipStream_t s) {
     uint32_t lnb = sh.c1;
     for (uint32_t n = sh.nsets; n > 1; n >>= 1) ++lnb;        // ~log2 of all buckets
-    const uint32_t want = lnb > 15 ? lnb - 15 : 0;            // ~1024 wavefronts in the first launch
+    const uint32_t want = lnb > 5 + log_waves ? lnb - 5 - log_waves : 0;   // ~2^log_waves wavefronts in the first launch (10: one per SIMD)
     const uint32_t sr = want < sh.cl - 6 ? want : sh.cl - 6, sc = want < sh.ch - 6 ? want : sh.ch - 6;
     const uint32_t nwave_row = sh.nsets << (sh.c1 - 6 - sr), nwave_col = sh.nsets << (sh.c1 - 6 - sc);
     hipLaunchKernelGGL(msm_rc2_sums_kernel, dim3((nwave_row + nwave_col + 3) / 4), dim3(256), 0, s, buckets, sh, sr, sc, nwave_row,
