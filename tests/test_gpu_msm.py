@@ -557,8 +557,13 @@ def test_chunked_pipeline_gives_identical_results(built, chunks, monkeypatch):
         c2.close()
 
 
-@pytest.mark.parametrize("scatter,l1", [("staged", "512"), ("staged", "256"), ("direct", "512")])
-def test_every_form_of_the_bucket_sort_gives_the_same_point(built, scatter, l1, monkeypatch):
+@pytest.mark.parametrize("scatter,l1,extra", [
+    ("staged", "512", {}), ("staged", "256", {}), ("direct", "512", {}),
+    # an unequal first chunk of a stand-alone MSM and the two-launch reduction with two wavefronts per SIMD on 2^19 buckets
+    # (measured and not adopted: profiles/r06_ab_first_chunk_and_rc2.txt; the switches stay, so they stay tested)
+    ("staged", "512", {"TYPLONK_MSM_FIRST_PCT": "30", "TYPLONK_MSM_REDUCE": "rc2", "TYPLONK_MSM_RC2_LOGW": "11"}),
+])
+def test_every_form_of_the_bucket_sort_gives_the_same_point(built, scatter, l1, extra, monkeypatch):
     """Round 6 rebuilt the bucket sort: level 1 stages its runs in the LDS (TYPLONK_MSM_SCATTER=direct keeps the rounds 1-5 form,
     also the fallback for shapes whose staging area does not fit), 256 or 512 threads per level-1 workgroup, level 2 assembles
     a segment's output in the LDS unless the segment is longer than its staging array.  Every form, at the table-mode sizes
@@ -571,6 +576,8 @@ def test_every_form_of_the_bucket_sort_gives_the_same_point(built, scatter, l1, 
 
     monkeypatch.setenv("TYPLONK_MSM_SCATTER", scatter)
     monkeypatch.setenv("TYPLONK_MSM_L1_THREADS", l1)
+    for k, v in extra.items():
+        monkeypatch.setenv(k, v)
     c2 = typlonk_amd.Context(0)
     try:
         length = (1 << 20) + (1 << 19) + 4
@@ -579,7 +586,7 @@ def test_every_form_of_the_bucket_sort_gives_the_same_point(built, scatter, l1, 
         c2.srs_precompute(tab, 20)
         small = c2.srs_generate(s_limbs, (1 << 17) + 9)
         c2.srs_precompute(small, 0)                                   # the library's choice for a shard: c = 17
-        rng = np.random.default_rng(int(l1) + len(scatter))
+        rng = np.random.default_rng(int(l1) + len(scatter) + len(extra))
         rep = [np.array(O.fr_to_mont_limbs(v), dtype=np.uint64) for v in O.random_frs(99, 2)]
         rm1 = np.array(O.fr_to_mont_limbs(O.R - 1), dtype=np.uint64)
 

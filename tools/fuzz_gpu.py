@@ -18,7 +18,8 @@ rng = np.random.default_rng(SEED)
 dev = torch.device("cuda", 0)
 R = O.R
 SORT_FORMS = [{}, {}, {"TYPLONK_MSM_SCATTER": "direct"}, {"TYPLONK_MSM_L1_THREADS": "256"}, {"TYPLONK_MSM_L1_THREADS": "512"},
-              {"TYPLONK_MSM_SORT_PRIO": "0"}, {"TYPLONK_NTT_BIG": "1"}, {"TYPLONK_NTT_BIG": "2"}]
+              {"TYPLONK_MSM_SORT_PRIO": "0"}, {"TYPLONK_NTT_BIG": "1"}, {"TYPLONK_NTT_BIG": "2"},
+              {"TYPLONK_MSM_FIRST_PCT": "30"}, {"TYPLONK_MSM_REDUCE": "rc2", "TYPLONK_MSM_RC2_LOGW": "11"}]
 SORT_KEYS = sorted({k for f in SORT_FORMS for k in f})
 
 
