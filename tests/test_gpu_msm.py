@@ -655,3 +655,68 @@ def test_more_than_2_23_terms_takes_the_counting_sort_fallback(ctx):
     buf.free()
     ctx.srs_free(sid)
     torch.cuda.empty_cache()
+
+
+def test_one_context_per_thread_two_threads_at_once(built):
+    """The threading contract of include/typlonk.h ("one host thread per context") as the Rust layer uses it
+    (integration/rust/kzg_hip: Backend::shared keeps one context per thread and device): two threads, each with its OWN
+    context on the same GPU, generate an SRS, build tables, commit (stand-alone MSMs of 2^17 + 5 and 2^20 + 1 terms, a batch of
+    four) and transform (single and grouped) AT THE SAME TIME -- ctypes releases the interpreter lock around every call -- and
+    every result equals the one a single thread computed before."""
+    import threading
+    import torch
+    import typlonk_amd
+
+    dev = torch.device("cuda", 0)
+    secret = np.array(O.fr_to_mont_limbs(0x51DE_CAFE), dtype=np.uint64)
+    length = (1 << 20) + 4
+    rng = np.random.default_rng(77)
+
+    def uniform(m):
+        sc = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * 2
+        sc[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)
+        return sc
+
+    work = [{"msm": [uniform((1 << 17) + 5), uniform((1 << 20) + 1)], "batch": [uniform(1 << 16) for _ in range(4)],
+             "ntt": uniform(1 << 18), "group": [uniform(1 << 14) for _ in range(3)]} for _ in range(2)]
+
+    def run(w, out):
+        c = typlonk_amd.Context(0)
+        try:
+            sid = c.srs_generate(secret, length)
+            c.srs_precompute(sid, 20)
+            res = {"msm": [], "rounds": 0}
+            for _ in range(3):                                         # several rounds, so that the threads really overlap
+                res["msm"] = [c.msm(sid, s) for s in w["msm"]]
+                vecs = [torch.from_numpy(np.ascontiguousarray(s).view(np.int64)).to(dev) for s in w["batch"]]
+                torch.cuda.synchronize()
+                res["batch"] = c.msm_batch_devptr(sid, [v.data_ptr() for v in vecs], [len(s) for s in w["batch"]])
+                res["ntt"] = c.ntt(w["ntt"], 18, inverse=True)
+                grp = [torch.from_numpy(np.ascontiguousarray(s).view(np.int64)).to(dev) for s in w["group"]]
+                torch.cuda.synchronize()
+                c.ntt_batch_devptr([g.data_ptr() for g in grp], 14)
+                torch.cuda.synchronize()
+                res["group"] = [g.cpu().numpy().view(np.uint64) for g in grp]
+                res["rounds"] += 1
+            out.update(res)
+        except BaseException as e:   # noqa: BLE001 -- reported by the asserting thread
+            out["error"] = repr(e)
+        finally:
+            c.close()
+
+    alone = [{}, {}]
+    for w, o in zip(work, alone):
+        run(w, o)
+    together = [{}, {}]
+    threads = [threading.Thread(target=run, args=(w, o)) for w, o in zip(work, together)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    for a, b in zip(alone, together):
+        assert "error" not in a and "error" not in b, (a.get("error"), b.get("error"))
+        assert b["rounds"] == 3
+        for (axy, ainf), (bxy, binf) in zip(a["msm"] + list(a["batch"]), b["msm"] + list(b["batch"])):
+            assert int(ainf) == int(binf) == 0 and (np.asarray(axy) == np.asarray(bxy)).all()
+        assert (a["ntt"] == b["ntt"]).all()
+        assert all((x == y).all() for x, y in zip(a["group"], b["group"]))
