@@ -68,6 +68,12 @@ void write_affine_out(const G1Affine& a, uint64_t out_xy[12], uint8_t* out_inf) 
     }
 }
 
+// stand-alone MSM over host scalars with the default chunking: a short first chunk (see msm_enqueue)
+static bool overlap_host_first(const typlonk_ctx* ctx, bool standalone, const uint64_t* h_scalars, uint32_t nch, size_t m) {
+    // (two default chunks only, i.e. 2^20 <= m < 3 * 2^19: at 2^22, eight chunks, the short first chunk costs 0.07 ms instead)
+    return standalone && h_scalars && nch == 2 && !ctx->msm_chunks && m >= ((size_t)1 << 20);
+}
+
 // Launch every kernel of one m-term MSM (m > 0, validated by the caller) on `stream` using workspace
 // `ws`, ending with the asynchronous copy of the W window sums into ws.host_wins.
 // h_scalars != NULL: the scalars are still on the HOST (typlonk_msm_g1: the reference's commit() hands over a Vec<Fr>); every
@@ -124,10 +130,19 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         // commitment of a 2^22-row proof).
         nch = (uint32_t)std::min<size_t>((m + ((size_t)1 << 20) - 1) >> 20, MSM_MAX_CHUNKS);
     }
-    // chunk k = terms [cut(k), cut(k + 1)): equal shares, or -- stand-alone MSMs, TYPLONK_MSM_FIRST_PCT -- a first chunk of
-    // that share of the terms (its sort is the exposed one) and equal shares of the rest
-    const size_t first = (standalone && nch > 1 && ctx->msm_first_pct > 0 && ctx->msm_first_pct < 100)
-                             ? std::max<size_t>(4096, (m / 100 * (size_t)ctx->msm_first_pct) & ~(size_t)63) : 0;
+    // chunk k = terms [cut(k), cut(k + 1)): equal shares, or a first chunk of its own size and equal shares of the rest:
+    //  * scalars in HOST memory (typlonk_msm_g1): the first chunk's copy over PCIe is the exposed one, so it is 2^18 terms (8 MB)
+    //    instead of 2^19 and there is one chunk more -- 2.73-2.75 -> 2.59-2.65 ms per 2^20-term commitment
+    //    (profiles/r06_ab_host_scalar_path.txt, calls U and V); device-resident scalars keep equal chunks (an unequal first
+    //    chunk loses there: profiles/r06_ab_first_chunk_and_rc2.txt);
+    //  * TYPLONK_MSM_FIRST_PCT: that share of the terms (experiments).
+    size_t first = 0;
+    if (standalone && nch > 1 && ctx->msm_first_pct > 0 && ctx->msm_first_pct < 100) {
+        first = std::max<size_t>(4096, (m / 100 * (size_t)ctx->msm_first_pct) & ~(size_t)63);
+    } else if (overlap_host_first(ctx, standalone, h_scalars, nch, m)) {
+        first = (size_t)1 << 18;
+        nch = std::min<uint32_t>(nch + 1, MSM_MAX_CHUNKS);
+    }
     const size_t step = first ? (m - first + nch - 2) / (nch - 1) : (m + nch - 1) / nch;
     auto cut = [&](uint32_t k) { return k == 0 ? (size_t)0 : std::min(m, first ? first + (size_t)(k - 1) * step : (size_t)k * step); };
     hipStream_t s = ws.stream;
