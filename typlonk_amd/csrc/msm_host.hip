@@ -119,8 +119,11 @@ int msm_enqueue(typlonk_ctx* ctx, MsmWs& ws, hipStream_t stream, const SrsEntry&
         // measured (tools/msm_chunks.py, profiles/r02_msm_chunks.jsonl): the overlapped sort is not free -- it competes
         // with the accumulation for issue slots -- and chunks of ~2^19 terms are the best grain: 2 chunks at 2^20
         // (2.76 -> 2.68 ms), 4 at 2^21 (5.09 -> 4.81), 8 at 2^22 (9.92 -> 8.99); below 2^20 one chunk wins
+        // (scalars still on the host: two chunks from 2^19 terms on, so that half of the copy hides -- 1.68 -> 1.57 ms at 2^19;
+        // neutral at 2^18, a loss at 2^17: profiles/r06_ab_host_scalar_path.txt, call W)
         nch = ctx->msm_chunks ? (uint32_t)ctx->msm_chunks
-                              : (m >= (1u << 20) ? (uint32_t)std::min<size_t>(m >> 19, MSM_MAX_CHUNKS) : 1u);
+                              : (m >= (1u << 20) ? (uint32_t)std::min<size_t>(m >> 19, MSM_MAX_CHUNKS)
+                                                 : (h_scalars && m >= (1u << 19) ? 2u : 1u));
         while (nch > 1 && m / nch < 4096) --nch;
     } else if (tables && m > ((size_t)1 << 20)) {
         // A queued MSM (a batch, a prover round) of more than 2^20 terms: chunks of <= 2^20 terms one after the other on the
