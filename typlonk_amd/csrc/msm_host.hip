@@ -773,6 +773,7 @@ int typlonk_g1_fold_records_host(const uint64_t* records, size_t world, size_t c
 }
 
 int typlonk_msm_plan(typlonk_ctx* ctx, size_t m, uint32_t* window_bits, uint32_t* n_windows, uint64_t* group_ops) {
+    (void)ctx;   // the plan of a plain MSM depends on the length only
     uint32_t c, W;
     msm_shape(m ? m : 1, &c, &W);
     if (window_bits) *window_bits = c;
