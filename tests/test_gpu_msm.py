@@ -720,3 +720,73 @@ def test_one_context_per_thread_two_threads_at_once(built):
             assert int(ainf) == int(binf) == 0 and (np.asarray(axy) == np.asarray(bxy)).all()
         assert (a["ntt"] == b["ntt"]).all()
         assert all((x == y).all() for x, y in zip(a["group"], b["group"]))
+
+
+def _fr_add_mod_limbs(a, b):
+    """(a + b) mod r on (m, 4) little-endian u64 limb arrays, vectorised (both inputs < r)"""
+    r_limbs = [np.uint64((O.R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for i in range(4)]
+    s = np.empty_like(a)
+    carry = np.zeros(a.shape[0], dtype=np.uint64)
+    for i in range(4):
+        t = a[:, i] + b[:, i]
+        c1 = t < a[:, i]
+        t2 = t + carry
+        c2 = t2 < t
+        s[:, i] = t2
+        carry = (c1 | c2).astype(np.uint64)
+    ge = np.ones(a.shape[0], dtype=bool)          # s >= r, decided from the top limb down
+    decided = np.zeros(a.shape[0], dtype=bool)
+    for i in (3, 2, 1, 0):
+        gt, lt = s[:, i] > r_limbs[i], s[:, i] < r_limbs[i]
+        ge = np.where(~decided & lt, False, ge)
+        decided |= gt | lt
+    d = np.empty_like(s)
+    borrow = np.zeros(a.shape[0], dtype=np.uint64)
+    for i in range(4):
+        t = s[:, i] - r_limbs[i]
+        b1 = s[:, i] < r_limbs[i]
+        t2 = t - borrow
+        b2 = t < borrow
+        d[:, i] = t2
+        borrow = (b1 | b2).astype(np.uint64)
+    return np.where(ge[:, None], d, s)
+
+
+@pytest.mark.parametrize("log_m", [20, 22])
+def test_msm_is_linear_in_the_scalars_at_full_size(ctx, log_m):
+    """A size-independent property at BASELINE's full sizes (2^20: config 3, 2^22: config 5): commit(a) + commit(b) ==
+    commit(a + b) -- over three different entry points, so that it also ties them together: a through typlonk_msm_g1 (scalars in
+    host memory, copied chunk by chunk), b through typlonk_msm_g1_devptr, a + b (and a again) through one
+    typlonk_msm_g1_batch_devptr call.  The sum of the two commitments is folded on the host (typlonk_g1_sum_host)."""
+    import torch
+    from typlonk_amd.capi import g1_sum_host
+
+    m = (1 << log_m) + 1
+    rng = np.random.default_rng(1000 + log_m)
+
+    def uniform():
+        x = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(m, 4), dtype=np.uint64)
+        x[:, 3] &= np.uint64(0x3FFFFFFFFFFFFFFF)       # < 2^254 < r
+        return x
+
+    a, b = uniform(), uniform()
+    # the helper against big integers on a sample (the edge of the reduction included: force one sum above r)
+    a[0], b[0] = np.array(O.fr_to_mont_limbs(5), dtype=np.uint64), np.array(O.fr_to_mont_limbs(O.R - 3), dtype=np.uint64)
+    ab = _fr_add_mod_limbs(a, b)
+    val = lambda l: sum(int(l[i]) << (64 * i) for i in range(4))   # noqa: E731
+    for i in (0, 1, 2, m // 2, m - 1):
+        assert val(ab[i]) == (val(a[i]) + val(b[i])) % O.R
+    sid = ctx.srs_generate(np.array(O.fr_to_mont_limbs(0xABCDE12345), dtype=np.uint64), m + 2)
+    ctx.srs_precompute(sid, 20)
+    dev = torch.device("cuda", 0)
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev)   # noqa: E731
+    da, db, dab = to_dev(a), to_dev(b), to_dev(ab)
+    torch.cuda.synchronize()
+    ca = ctx.msm(sid, a)
+    cb = ctx.msm_devptr(sid, db.data_ptr(), m)
+    cab, ca2 = ctx.msm_batch_devptr(sid, [dab.data_ptr(), da.data_ptr()], [m, m])
+    assert int(ca[1]) == int(cb[1]) == int(cab[1]) == 0
+    assert (np.asarray(ca2[0]) == np.asarray(ca[0])).all()
+    sxy, sinf = g1_sum_host(np.stack([np.asarray(ca[0]), np.asarray(cb[0])]), np.zeros(2, dtype=np.uint8))
+    assert sinf == 0 and (sxy == np.asarray(cab[0])).all()
+    ctx.srs_free(sid)
