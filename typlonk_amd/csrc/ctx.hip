@@ -108,6 +108,7 @@ int typlonk_init(typlonk_ctx** out, int device_ordinal) {
     if (const char* e = getenv("TYPLONK_MSM_CHUNKS")) ctx->msm_chunks = std::max(0, std::min(atoi(e), MSM_MAX_CHUNKS));
     if (const char* e = getenv("TYPLONK_MSM_FIRST_PCT")) ctx->msm_first_pct = std::max(0, std::min(atoi(e), 99));
     if (const char* e = getenv("TYPLONK_PROVER_PIPE")) ctx->prover_pipe = atoi(e) != 0;
+    if (const char* e = getenv("TYPLONK_PROVER_FETCH")) ctx->prover_pinned_slots = atoi(e) != 0;
     if (const char* e = getenv("TYPLONK_PROVER_NTT_BATCH")) ctx->prover_ntt_batch = std::max(0, std::min(atoi(e), 3));
     if (const char* e = getenv("TYPLONK_NTT_FR30")) ctx->ntt_fr30 = std::max(0, std::min(atoi(e), 2));
     if (const char* e = getenv("TYPLONK_NTT_BIG")) ctx->ntt_big = std::max(0, std::min(atoi(e), 2));
@@ -129,6 +130,7 @@ void typlonk_destroy(typlonk_ctx* ctx) {
         (void)hipFree(kv.second.sig_ev);
     }
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.d);
+    if (ctx->eval_slots_host) (void)hipHostFree(ctx->eval_slots_host);
     for (DevBuf* b : {&ctx->srs_comb, &ctx->scal, &ctx->ntt_scratch, &ctx->ntt_io, &ctx->quot_ext, &ctx->quot_tab, &ctx->ops_tmp, &ctx->prover_mem}) release(*b);
     for (MsmWs& ws : ctx->ws) {
         for (SortBufs& sb : ws.sb)

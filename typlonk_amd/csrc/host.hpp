@@ -175,6 +175,8 @@ struct typlonk_ctx {
                                    // already hidden beside the commitments' sorts; the batched entry point pays where nothing
                                    // runs beside it (typlonk_circuit_load, a caller's interpolate groups)
     bool prover_pipe = true;       // TYPLONK_PROVER_PIPE (A/B switch of the round-5 queueing fix, prover_round3_core)
+    bool prover_pinned_slots = true;  // the prover's evaluation slots in pinned host memory (TYPLONK_PROVER_FETCH=0: device slots + copy)
+    tyh::Fr* eval_slots_host = nullptr;  // 16 pinned, device-visible result slots (prover_ops_tmp)
     int msm_chunks = 0;            // chunks of a stand-alone MSM (0 = choose by length)
     int msm_first_pct = 0;         // share of the terms in the first chunk, per cent (0 = equal chunks)
     int msm_lanes = 0;             // lanes per bucket of the accumulation (0 = choose by bucket load)

@@ -361,7 +361,11 @@ int prover_extend_batch(typlonk_prover* p, const int* ks, const Fr* const* coeff
         for (size_t i = 0; i < count; ++i) p->extended |= 1u << ks[i];
     return rc;
 }
-// ops_tmp layout of the prover's openings: [0, 8*2048) per-workgroup carries, then 16 result slots
+// ops_tmp layout of the prover's openings: [0, 8*2048) per-workgroup carries, then 16 result slots.
+// The slots are only ever WRITTEN by kernels (p(z) of an opening) and read by the host, so they live in pinned host memory the
+// kernels store into directly: a fetch is one stream synchronisation, no copy.  (Device slots + hipMemcpyAsync into a stack
+// array -- pageable, so staged by the runtime -- left the GPU idle for ~170 us before the linearisation and ~120 us before
+// round 3's commitments, profiles/r06_prove_timeline.txt 15.50-15.67 and 15.89-16.02 ms.)
 constexpr size_t PROVER_EVAL_BLOCKS = 8 * 2048;
 int prover_ops_tmp(typlonk_prover* p, Fr** blocks, Fr** slots) {
     typlonk_ctx* ctx = p->ctx;
@@ -369,6 +373,10 @@ int prover_ops_tmp(typlonk_prover* p, Fr** blocks, Fr** slots) {
     if (rc) return rc;
     *blocks = (Fr*)ctx->ops_tmp.p;
     *slots = *blocks + PROVER_EVAL_BLOCKS;
+    if (ctx->prover_pinned_slots) {
+        if (!ctx->eval_slots_host) HIPCHK(hipHostMalloc((void**)&ctx->eval_slots_host, 16 * sizeof(Fr)));
+        *slots = ctx->eval_slots_host;
+    }
     return TYPLONK_OK;
 }
 // open() without waiting: p(z) lands in result slot `slot`, the quotient (if q) in q; stream-ordered
@@ -387,6 +395,11 @@ int prover_fetch(typlonk_prover* p, Fr* out, int count) {
     Fr *blocks, *slots;
     int rc = prover_ops_tmp(p, &blocks, &slots);
     if (rc) return rc;
+    if (ctx->prover_pinned_slots) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        memcpy((void*)out, (const void*)slots, (size_t)count * sizeof(Fr));
+        return TYPLONK_OK;
+    }
     HIPCHK(hipMemcpyAsync(out, slots, (size_t)count * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return TYPLONK_OK;
@@ -707,7 +720,12 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
         hipError_t he = hipGetLastError();
         if (he != hipSuccess) rc = fail(ctx, TYPLONK_ERR_HIP, hipGetErrorString(he));
     }
-    if (!rc) rc = prover_open(p, p->r, n, ze, batched ? nullptr : p->q[5], &ev[5]);          // proof.rs:175
+    // r(zeta) and its witness polynomial (proof.rs:175).  The reference shape does not wait for the value here: it is an
+    // OUTPUT (and the r(zeta) != 0 check), nothing of this round's commitments depends on it -- it is read from its pinned slot
+    // once the commitments have been waited for, and the first sort starts without a drain of the context's stream in between.
+    const bool late_r = !batched && ctx->prover_pinned_slots;
+    if (!rc) rc = late_r ? prover_open_async(p, p->r, n, ze, p->q[5], 0)
+                         : prover_open(p, p->r, n, ze, batched ? nullptr : p->q[5], &ev[5]);
     if (!rc && batched) {
         // evaluations only: every commitment of this shape is issued by round4_batched in ONE five-MSM batch
         for (int i = 0; i < 6; ++i) memcpy(evals_out->evals[i], ev[i].v, 32);
@@ -734,6 +752,7 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
             const int r = q.wait_all();
             if (!rc) rc = r;
         }
+        if (!rc && late_r) rc = prover_fetch(p, &ev[5], 1);   // (every lane has been waited for: this returns at once)
         if (!rc) {
             memcpy(out->w_xy, xy, 6 * 96);
             memcpy(out->w_inf, inf, 6);
