@@ -626,6 +626,8 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
     const Fr w = fr_domain_root(log_n);
     const Fr zw = fe_mul(ze, w);
     Fr s0, s1, pi_z = Fr::zero();
+    const Fr one = Fr::one();
+    Fr zn = ze, zh = one, l0z = one;   // zeta^n, Z_H(zeta), L0(zeta): filled under the kernels, before the wait
     {
         // ONE synchronisation for everything evaluated here.  Result slots: 0..3 = a, b, c, Z at zeta (with their
         // quotients unless batched), 4, 5 = sigma_0, sigma_1 and 6 = the public-input polynomial at zeta (for the
@@ -674,6 +676,14 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
             qa.circuit = p->circuit;
             rc = quotient_run(ctx, &qa, log_n, &tb, p->extended);
         }
+        // what the linearisation needs of zeta alone (one host inversion among it): while the kernels above run
+        for (uint32_t i = 0; i < log_n; ++i) zn = fe_sqr(zn);
+        zh = fe_sub(zn, one);  // evaluate_vanishing_polynomial(zeta)
+        {
+            // L0(zeta) = (zeta^n - 1) / (n (zeta - 1)); the polynomial (1/n) sum X^i evaluates to 1 at zeta = 1
+            const Fr zm1 = fe_sub(ze, one);
+            if (!zm1.is_zero()) l0z = fe_mul(zh, fe_inv(fe_mul(fr_from_u64(n), zm1)));
+        }
         if (!rc) rc = prover_fetch(p, host, 9);
         for (int i = 0; i < 4; ++i) ev[i] = host[i];
         ev[4] = host[8];
@@ -682,14 +692,6 @@ int prover_round3_core(typlonk_prover* p, const uint64_t alpha[4], const uint64_
         if (p->has_pi) pi_z = host[6];
     }
     if (!rc) {
-        const Fr one = Fr::one();
-        Fr zn = ze;  // zeta^n
-        for (uint32_t i = 0; i < log_n; ++i) zn = fe_sqr(zn);
-        const Fr zh = fe_sub(zn, one);  // evaluate_vanishing_polynomial(zeta)
-        // L0(zeta) = (zeta^n - 1) / (n (zeta - 1)); the polynomial (1/n) sum X^i evaluates to 1 at zeta = 1
-        Fr l0z = one;
-        const Fr zm1 = fe_sub(ze, one);
-        if (!zm1.is_zero()) l0z = fe_mul(zh, fe_inv(fe_mul(fr_from_u64(n), zm1)));
         const Fr &a = ev[0], &b = ev[1], &c = ev[2], &zwe = ev[4];
         const Fr &beta = p->beta, &gamma = p->gamma;
         const Fr bz = fe_mul(beta, ze);
